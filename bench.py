@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the 23-block RRDBNet x4 (128x128 -> 512x512), fp32 inference,
+batch 16 per GPU (BASELINE.json configs[1]); one "step" = one forward of the batch, inputs resident
+in HBM.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: images are independent, so ranks shard the tiles with no data-path collective (weak
+scaling: 16 tiles per GPU); the only collectives are the timing barrier and the max over ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32)
+BATCH = 16
+TILE = 128
+PEAK_F32_TFLOPS = 157.3   # MI355X fp32 MFMA (v_mfma_f32_32x32x2_f32), /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+FLOPS_PER_IMAGE = 5.8743e11
+
+
+def cpu_baseline():
+    """Oracle (CPU restatement of the reference, PyTorch CPU fp32) on this host's cores, bounded sample."""
+    from image_restoration_amd.utils import synth
+    from oracle import rrdbnet_ref as R
+    sd = {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    x = torch.from_numpy(synth.uniform_input(1234, (2, 3, TILE, TILE)))
+    with torch.no_grad():
+        R.rrdbnet_forward(x[:1, :, :32, :32], sd, 4, CFG['num_block'])  # warm-up (thread pool, allocator)
+        best = float('inf')
+        t_all = time.perf_counter()
+        reps = 0
+        while reps < 3 and time.perf_counter() - t_all < 40:
+            t0 = time.perf_counter()
+            R.rrdbnet_forward(x, sd, 4, CFG['num_block'])
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+    return {'value': round(x.shape[0] / best, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'best of {reps} forwards of 2 of the 16 128x128 tiles, oracle/rrdbnet_ref.py (PyTorch CPU fp32, '
+                      f'{torch.get_num_threads()} threads)'}
+
+
+def kernel_rooflines(net, x):
+    """One extra forward with HIP events around every conv launch (sr_profile_*), on the stream the
+    kernels run on.  Returns per-kernel aggregates; the dominant one (most time) is the roofline line."""
+    from image_restoration_amd import _lib
+    lib = _lib.load()
+    cap = 1024
+    recs = (_lib.LaunchRecord * cap)()
+    n = C.c_int(0)
+    _lib.check(lib.sr_profile_start(cap), 'sr_profile_start')
+    with torch.no_grad():
+        net(x)
+    _lib.check(lib.sr_profile_stop(recs, cap, C.byref(n)), 'sr_profile_stop')
+    agg = {}
+    for r in recs[:n.value]:
+        a = agg.setdefault(r.kernel_id, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        a['launches'] += 1
+        a['ms'] += r.ms
+        a['flops'] += r.flops
+        a['bytes'] += r.bytes
+    out = []
+    for kid, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+        tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        gbs = a['bytes'] / (a['ms'] * 1e-3) / 1e9
+        out.append({'kernel': lib.sr_kernel_name(kid).decode(), 'launches': a['launches'],
+                    'avg_ms': round(a['ms'] / a['launches'], 5), 'total_ms': round(a['ms'], 4),
+                    'tflops': round(tf, 2), 'flop_frac': round(tf / PEAK_F32_TFLOPS, 4),
+                    'alg_gbs': round(gbs, 1), 'hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
+                    'alg_flops_per_launch': a['flops'] / a['launches'], 'alg_bytes_per_launch': a['bytes'] / a['launches']})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    import image_restoration_amd as ira
+    from image_restoration_amd.utils import synth
+    net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
+    x = torch.from_numpy(synth.uniform_input(1234 + rank, (BATCH, 3, TILE, TILE))).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = net(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = net(x)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(y).all())
+
+    if rank == 0:
+        value = world * BATCH * args.steps / dt
+        line = {
+            'metric': 'images/sec (128x128->512x512 x4 SR, 23-block RRDBNet)', 'value': round(value, 3),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: RRDBNet num_block=23 nf=64 x4 fp32 inference, batch 16 of '
+                                   '128x128 tiles per GPU', 'global_batch': world * BATCH, 'tile': TILE,
+                       'parallelism': f'tile-sharded x{world}, no data-path collective'},
+            'net_tflops': round(value * FLOPS_PER_IMAGE / 1e12 / world, 2),
+        }
+        if world == 1:
+            ks = kernel_rooflines(net, x)
+            k0 = ks[0]
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(k0['kernel'])
+            line['roofline'] = {'bound': 'mfma', 'achieved': k0['tflops'], 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': k0['flop_frac'], 'traffic': traffic, 'kernel': k0['kernel'],
+                                'avg_launch_ms': k0['avg_ms'], 'hbm_frac_algorithmic': k0['hbm_frac']}
+            line['kernels'] = ks
+            if not args.no_cpu_baseline:
+                line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

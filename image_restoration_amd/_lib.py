@@ -1,0 +1,102 @@
+"""ctypes binding of libsr_hip.so (C ABI declared in include/sr_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails the
+caller gets an exception.  The product path never routes through ``oracle/`` or
+through PyTorch CPU/ATen convolutions.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsr_hip.so')
+
+SR_ABI_VERSION = 1
+
+
+class SrHipError(RuntimeError):
+    """Raised when a libsr_hip.so entry point returns a non-zero status."""
+
+
+class ConvDesc(C.Structure):
+    """struct sr_conv3x3_desc (include/sr_hip.h)."""
+    _fields_ = [
+        ('in_', C.c_void_p), ('in_img_stride', C.c_int64), ('cin_pad', C.c_int), ('cin_real', C.c_int), ('in_h', C.c_int), ('in_w', C.c_int),
+        ('upsample', C.c_int), ('wpacked', C.c_void_p), ('bpacked', C.c_void_p), ('cout', C.c_int),
+        ('out', C.c_void_p), ('out_img_stride', C.c_int64), ('out_nchw', C.c_int), ('n', C.c_int),
+        ('act_slope', C.c_float), ('alpha', C.c_float),
+        ('res1', C.c_void_p), ('res1_img_stride', C.c_int64), ('beta1', C.c_float),
+        ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float),
+        ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
+        ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float),
+    ]
+
+
+class RRDBNetCfg(C.Structure):
+    """struct sr_rrdbnet_cfg (include/sr_hip.h)."""
+    _fields_ = [('num_in_ch', C.c_int), ('num_out_ch', C.c_int), ('scale', C.c_int), ('num_feat', C.c_int),
+                ('num_block', C.c_int), ('num_grow_ch', C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/sr_hip.h declares
+SIGNATURES = {
+    'sr_version': (C.c_int, []),
+    'sr_last_error': (C.c_char_p, []),
+    'sr_nchw_to_cb8_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int64, C.c_void_p]),
+    'sr_cb8_to_nchw_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
+    'sr_conv3x3_packed_weight_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'sr_conv3x3_packed_bias_floats': (C.c_size_t, [C.c_int]),
+    'sr_conv3x3_cin_pad': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'sr_conv3x3_pack_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_conv3x3_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'sr_rrdbnet_num_params': (C.c_int, [C.POINTER(RRDBNetCfg)]),
+    'sr_rrdbnet_packed_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
+    'sr_rrdbnet_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_pack_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'sr_rrdbnet_forward_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+
+
+class LaunchRecord(C.Structure):
+    """struct sr_launch_record (include/sr_hip.h)."""
+    _fields_ = [('kernel_id', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32), ('n', C.c_int32), ('h', C.c_int32),
+                ('w', C.c_int32), ('flops', C.c_double), ('bytes', C.c_double), ('ms', C.c_float)]
+
+
+SIGNATURES.update({
+    'sr_profile_start': (C.c_int, [C.c_int]),
+    'sr_profile_stop': (C.c_int, [C.POINTER(LaunchRecord), C.c_int, C.POINTER(C.c_int)]),
+    'sr_kernel_name': (C.c_char_p, [C.c_int]),
+})
+
+_lib = None
+
+
+def load():
+    """Loads libsr_hip.so (once).  Raises if it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrHipError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                         '(or `make -C image_restoration_amd/csrc`). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.sr_version()
+    if v != SR_ABI_VERSION:
+        raise SrHipError(f'libsr_hip.so ABI {v} != expected {SR_ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sr_last_error().decode('utf-8', 'replace')
+        raise SrHipError(f'{what} failed (status {rc}): {msg}')

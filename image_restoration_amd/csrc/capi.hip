@@ -1,0 +1,80 @@
+// Error reporting and ABI version of libsr_hip.so.
+#include <string.h>
+
+#include "sr_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+namespace sr {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace sr
+
+extern "C" int sr_version(void) { return SR_ABI_VERSION; }
+extern "C" const char* sr_last_error(void) { return g_err; }
+
+// ---- opt-in launch profiler (thread-local; off unless sr_profile_start was called) ----
+#include <vector>
+
+namespace {
+struct ProfState {
+  bool on = false;
+  size_t cap = 0;
+  std::vector<sr_launch_record> recs;
+  std::vector<hipEvent_t> ev;  // 2 per record
+};
+thread_local ProfState g_prof;
+}  // namespace
+
+namespace sr {
+bool prof_on() { return g_prof.on && g_prof.recs.size() < g_prof.cap; }
+void prof_begin(hipStream_t s, const sr_launch_record& r) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, s);
+  g_prof.recs.push_back(r);
+  g_prof.ev.push_back(a);
+  g_prof.ev.push_back(b);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.ev.back(), s); }
+}  // namespace sr
+
+extern "C" int sr_profile_start(int max_records) {
+  SR_CHECK_ARG(max_records > 0, "sr_profile_start: max_records must be positive");
+  SR_CHECK_ARG(!g_prof.on, "sr_profile_start: already recording");
+  g_prof.on = true;
+  g_prof.cap = (size_t)max_records;
+  g_prof.recs.clear();
+  g_prof.ev.clear();
+  return SR_OK;
+}
+
+extern "C" int sr_profile_stop(sr_launch_record* out, int capacity, int* count) {
+  SR_CHECK_ARG(g_prof.on, "sr_profile_stop: not recording");
+  g_prof.on = false;
+  int rc = SR_OK;
+  const int n = (int)g_prof.recs.size();
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
+      sr::set_error("sr_profile_stop: event %d failed", i);
+      rc = SR_ELAUNCH;
+    }
+    g_prof.recs[i].ms = ms;
+    if (out && i < capacity) out[i] = g_prof.recs[i];
+    (void)hipEventDestroy(g_prof.ev[2 * i]);
+    (void)hipEventDestroy(g_prof.ev[2 * i + 1]);
+  }
+  if (count) *count = n;
+  g_prof.recs.clear();
+  g_prof.ev.clear();
+  return rc;
+}

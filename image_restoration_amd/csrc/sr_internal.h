@@ -1,0 +1,36 @@
+// Internal helpers shared by the HIP translation units of libsr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/sr_hip.h"
+
+namespace sr {
+
+void set_error(const char* fmt, ...);
+bool prof_on();
+void prof_begin(hipStream_t s, const sr_launch_record& r);
+void prof_end(hipStream_t s);
+
+#define SR_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::sr::set_error(__VA_ARGS__);        \
+      return SR_EINVAL;                    \
+    }                                      \
+  } while (0)
+
+#define SR_CHECK_LAUNCH(what)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      ::sr::set_error("%s: %s", what, hipGetErrorString(e__));                  \
+      return SR_ELAUNCH;                                                        \
+    }                                                                           \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace sr

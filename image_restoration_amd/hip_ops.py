@@ -1,0 +1,147 @@
+"""Thin torch-tensor wrappers over the C ABI (include/sr_hip.h).
+
+Tensors only provide device memory and the current HIP stream; every op below is one
+libsr_hip.so call.  Activations between ops are in the CB8 layout
+``[N][C/8][H][W][8]`` (class ``CB8``); channel slices are views (pointer + parent stride).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.SrHipError(f'{what}: tensor is on {t.device}; the HIP path has no CPU fallback')
+
+
+class CB8:
+    """A channel-blocked fp32 activation: storage ``buf`` [N, CB, H, W, 8] plus a channel-block window."""
+
+    def __init__(self, buf, cb0=0, cbn=None):
+        assert buf.dim() == 5 and buf.size(4) == 8 and buf.dtype == torch.float32 and buf.is_contiguous()
+        self.buf, self.cb0 = buf, cb0
+        self.cbn = buf.size(1) - cb0 if cbn is None else cbn
+        assert 0 <= cb0 and cb0 + self.cbn <= buf.size(1)
+
+    @staticmethod
+    def empty(n, channels, h, w, device):
+        return CB8(torch.empty((n, (channels + 7) // 8, h, w, 8), dtype=torch.float32, device=device))
+
+    @staticmethod
+    def zeros(n, channels, h, w, device):
+        return CB8(torch.zeros((n, (channels + 7) // 8, h, w, 8), dtype=torch.float32, device=device))
+
+    n = property(lambda s: s.buf.size(0))
+    h = property(lambda s: s.buf.size(2))
+    w = property(lambda s: s.buf.size(3))
+    channels = property(lambda s: s.cbn * 8)
+    img_stride = property(lambda s: s.buf.size(1) * s.buf.size(2) * s.buf.size(3) * 8)
+    device = property(lambda s: s.buf.device)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.cb0 * self.h * self.w * 8 * 4
+
+    def slice(self, c0, c):
+        assert c0 % 8 == 0 and c % 8 == 0
+        return CB8(self.buf, self.cb0 + c0 // 8, c // 8)
+
+
+def nchw_to_cb8(x, unshuffle=1, out=None):
+    _need_cuda(x, 'nchw_to_cb8')
+    lib = _lib.load()
+    x = x.contiguous().float()
+    n, c, hh, ww = x.shape
+    h, w = hh // unshuffle, ww // unshuffle
+    cu = c * unshuffle * unshuffle
+    if out is None:
+        out = CB8.empty(n, cu, h, w, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.sr_nchw_to_cb8_f32(x.data_ptr(), out.ptr, n, c, h, w, unshuffle, out.cbn, out.img_stride,
+                                          _stream(x.device)), 'sr_nchw_to_cb8_f32')
+    return out
+
+
+def cb8_to_nchw(t, channels):
+    lib = _lib.load()
+    y = torch.empty((t.n, channels, t.h, t.w), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(lib.sr_cb8_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w,
+                                          _stream(t.device)), 'sr_cb8_to_nchw_f32')
+    return y
+
+
+class PackedConv:
+    """MFMA operand image of one 3x3 conv (sr_conv3x3_pack_f32)."""
+
+    def __init__(self, weight, bias=None, first_seg=None, seg=0, mode=0):
+        _need_cuda(weight, 'PackedConv')
+        lib = _lib.load()
+        weight = weight.detach().contiguous().float()
+        cout, cin = weight.shape[:2]
+        assert weight.shape[2:] == (3, 3)
+        first_seg = cin if first_seg is None else first_seg
+        self.cin_pad = lib.sr_conv3x3_cin_pad(cin, first_seg, seg)
+        if self.cin_pad <= 0:
+            raise ValueError(f'cin={cin} is not first_seg={first_seg} + k*seg={seg}')
+        self.mode = mode
+        if mode == 0:
+            self.cout, self.src_channels = cout, self.cin_pad
+            nw = lib.sr_conv3x3_packed_weight_floats(cout, self.cin_pad)
+        else:
+            self.cout, self.src_channels = self.cin_pad, (cout + 7) // 8 * 8
+            nw = lib.sr_conv3x3_packed_weight_floats(self.cin_pad, self.src_channels)
+        dev = weight.device
+        self.w = torch.empty(nw, dtype=torch.float32, device=dev)
+        self.b = None
+        if mode == 0 and bias is not None:
+            bias = bias.detach().contiguous().float()
+            self.b = torch.empty(lib.sr_conv3x3_packed_bias_floats(cout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_conv3x3_pack_f32(weight.data_ptr(), bias.data_ptr() if self.b is not None else None,
+                                               cout, cin, first_seg, seg, mode, self.w.data_ptr(),
+                                               self.b.data_ptr() if self.b is not None else None, _stream(dev)),
+                       'sr_conv3x3_pack_f32')
+
+
+def conv3x3(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
+            beta2=0.0, accumulate=False, mask=None, mask_cb0=0, mask_slope=0.2, out_nchw=None):
+    """out = alpha*lrelu(conv(src)+bias) + beta1*res1 + beta2*res2  (one sr_conv3x3_f32 launch).
+
+    src: CB8 window of pc.src_channels channels.  out: CB8 window (allocated if None) or, with
+    ``out_nchw`` = an NCHW tensor [N, cout<=4, H, W], a plain tensor."""
+    lib = _lib.load()
+    assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
+    H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
+    d = _lib.ConvDesc()
+    d.in_, d.in_img_stride, d.cin_pad, d.in_h, d.in_w = src.ptr, src.img_stride, pc.src_channels, src.h, src.w
+    d.upsample = int(upsample)
+    d.wpacked, d.bpacked, d.cout = pc.w.data_ptr(), (pc.b.data_ptr() if pc.b is not None else None), pc.cout
+    if out_nchw is not None:
+        assert out_nchw.is_contiguous() and out_nchw.shape == (src.n, pc.cout, H, W)
+        d.out, d.out_img_stride, d.out_nchw = out_nchw.data_ptr(), pc.cout * H * W, 1
+        ret = out_nchw
+    else:
+        if out is None:
+            out = CB8.empty(src.n, pc.cout, H, W, src.device)
+        assert (out.n, out.h, out.w) == (src.n, H, W) and out.channels >= (pc.cout + 7) // 8 * 8
+        d.out, d.out_img_stride, d.out_nchw = out.ptr, out.img_stride, 0
+        ret = out
+    d.n, d.act_slope, d.alpha = src.n, act_slope, alpha
+    if res1 is not None:
+        d.res1, d.res1_img_stride, d.beta1 = res1.ptr, res1.img_stride, beta1
+    if res2 is not None:
+        d.res2, d.res2_img_stride, d.beta2 = res2.ptr, res2.img_stride, beta2
+    d.accumulate = int(accumulate)
+    if mask is not None:
+        d.mask_src, d.mask_img_stride, d.mask_cb0, d.mask_cbn, d.mask_slope = (mask.ptr, mask.img_stride, mask_cb0,
+                                                                               mask.cbn, mask_slope)
+    with torch.cuda.device(src.device):
+        _lib.check(lib.sr_conv3x3_f32(C.byref(d), _stream(src.device)), 'sr_conv3x3_f32')
+    return ret

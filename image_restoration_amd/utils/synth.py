@@ -1,0 +1,85 @@
+"""Deterministic synthetic parameters and inputs (numpy PCG64: stable across versions).
+
+Never relies on torch's RNG streams, so the same seed gives the same network here, in the
+golden generator (which loads them into the REFERENCE modules) and on the GPU box.
+RDB conv weights ~ N(0, (0.1*sqrt(2/fan_in))^2) like the reference initialisation
+(arch_util.py:12-40 with scale 0.1), other convs ~ U(+-1/sqrt(fan_in)); biases are small and
+NON-zero so bias paths are exercised.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+
+def rrdbnet_param_shapes(num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32):
+    """(name, shape) in state_dict order of RRDBNet (rrdbnet_arch.py:94-101)."""
+    cin = num_in_ch * {4: 1, 2: 4, 1: 16}.get(scale, 1)
+    out = []
+
+    def conv(name, ci, co):
+        out.append((f'{name}.weight', (co, ci, 3, 3)))
+        out.append((f'{name}.bias', (co,)))
+
+    conv('conv_first', cin, num_feat)
+    for b in range(num_block):
+        for r in (1, 2, 3):
+            for k in range(1, 5):
+                conv(f'body.{b}.rdb{r}.conv{k}', num_feat + (k - 1) * num_grow_ch, num_grow_ch)
+            conv(f'body.{b}.rdb{r}.conv5', num_feat + 4 * num_grow_ch, num_feat)
+    for name in ('conv_body', 'conv_up1', 'conv_up2', 'conv_hr'):
+        conv(name, num_feat, num_feat)
+    conv('conv_last', num_feat, num_out_ch)
+    return out
+
+
+def conv_params(rng, shape_w, rdb_style, bias_scale=0.05):
+    co, ci, kh, kw = shape_w
+    fan_in = ci * kh * kw
+    if rdb_style:
+        w = rng.standard_normal(shape_w, dtype=np.float32) * np.float32(0.1 * math.sqrt(2.0 / fan_in))
+    else:
+        bound = 1.0 / math.sqrt(fan_in)
+        w = (rng.random(shape_w, dtype=np.float32) * 2 - 1) * np.float32(bound)
+    b = (rng.random((co,), dtype=np.float32) * 2 - 1) * np.float32(bias_scale)
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def rrdbnet_state_dict(seed=0, **cfg):
+    """OrderedDict name -> np.float32 array for RRDBNet(**cfg)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    shapes = rrdbnet_param_shapes(**cfg)
+    for i in range(0, len(shapes), 2):
+        (wn, ws), (bn, _) = shapes[i], shapes[i + 1]
+        w, b = conv_params(rng, ws, rdb_style='.rdb' in wn)
+        sd[wn], sd[bn] = w, b
+    return sd
+
+
+def rdb_state_dict(seed, num_feat=64, num_grow_ch=32, prefix=''):
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for k in range(1, 6):
+        ci = num_feat + (k - 1) * num_grow_ch
+        co = num_grow_ch if k < 5 else num_feat
+        w, b = conv_params(rng, (co, ci, 3, 3), rdb_style=True)
+        sd[f'{prefix}conv{k}.weight'], sd[f'{prefix}conv{k}.bias'] = w, b
+    return sd
+
+
+def rrdb_state_dict(seed, num_feat=64, num_grow_ch=32):
+    sd = OrderedDict()
+    for r in (1, 2, 3):
+        sd.update(rdb_state_dict(seed * 10 + r, num_feat, num_grow_ch, prefix=f'rdb{r}.'))
+    return sd
+
+
+def uniform_input(seed, shape):
+    """U[0,1) fp32 images, the benchmark's synthetic input."""
+    return np.random.default_rng(seed).random(shape, dtype=np.float32)
+
+
+def signed_input(seed, shape, scale=1.0):
+    """Zero-mean features for block-level tests."""
+    return ((np.random.default_rng(seed).random(shape, dtype=np.float32) * 2 - 1) * np.float32(scale)).astype(np.float32)

@@ -1,0 +1,159 @@
+/*
+ * sr_hip.h — C ABI of the MI355X (gfx950) RRDBNet/ESRGAN hot path.
+ *
+ * The reference (ChuRuaNh0/Image_Restoration, BasicSR 1.3.3.10 fork) has NO native
+ * interface for this path: RRDBNet is a Python nn.Module whose arithmetic is
+ * torch.nn.Conv2d / LeakyReLU / cat / interpolate.  The entry points
+ * below are therefore "what an FFI for this path would bind": each one names the
+ * reference Python it replaces.  Host code (the image_restoration_amd package) reaches them
+ * through ctypes; a C/C++ host can link libsr_hip.so directly.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SR_E* code on failure;
+ *    sr_last_error() returns a thread-local message for the last failure.
+ *  - all pointers are DEVICE pointers unless a parameter is named host_*.
+ *  - `stream` is the caller's hipStream_t passed as void*; every launch goes to exactly that
+ *    stream (NULL = HIP's default stream, which is what torch.cuda.current_stream() is
+ *    unless the caller selected another).  The library holds no stream of its own and is
+ *    re-entrant per stream (SURVEY.md §8b "Threading").
+ *  - no function allocates device memory or synchronises the device; workspaces
+ *    are sized by the *_bytes() helpers and owned by the caller (graph-capturable).
+ *
+ * Device activation layout "CB8" (channel-blocked, 32-byte pixels):
+ *    float feat[N][C/8][H][W][8]     (C padded up to a multiple of 8 with zeros)
+ * A channel slice [c0, c0+C') with c0 % 8 == 0 of a wider CB8 tensor is the same
+ * layout at pointer + (c0/8)*H*W*8 with the parent's image stride, which is how the
+ * dense block's torch.cat (rrdbnet_arch.py:34-37) is never materialised.
+ */
+#ifndef SR_HIP_H
+#define SR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define SR_ELAUNCH (-2)  /* HIP launch/runtime error */
+#define SR_ENOSPACE (-3) /* workspace too small */
+
+#define SR_ABI_VERSION 1
+
+/* ABI version of this library (SR_ABI_VERSION it was built with). */
+int sr_version(void);
+/* Message of the last error on this thread ("" if none). */
+const char* sr_last_error(void);
+
+/* ---------------------------------------------------------------- layout ---- */
+
+/* NCHW fp32 (caller tensor) -> CB8.  `unshuffle` in {1,2,4} fuses the reference's
+ * pixel_unshuffle (arch_util.py:185-201, used by RRDBNet.forward :106-109): the
+ * source is [N][C][H*u][W*u] and the CB8 tensor has C*u*u channels at H x W.
+ * dst has `dst_cblocks` channel blocks (>= ceil(C*u*u/8)); pad channels are zeroed. */
+int sr_nchw_to_cb8_f32(const float* src, float* dst, int N, int C, int H, int W, int unshuffle,
+                       int dst_cblocks, int64_t dst_img_stride, void* stream);
+/* CB8 -> NCHW fp32, first C channels. */
+int sr_cb8_to_nchw_f32(const float* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W,
+                       void* stream);
+
+/* ------------------------------------------------------------- conv3x3 ------ */
+
+/* Number of floats of the packed weight / packed bias image of one 3x3 conv with
+ * `cin_pad` (multiple of 8) input and `cout` output channels. */
+size_t sr_conv3x3_packed_weight_floats(int cout, int cin_pad);
+size_t sr_conv3x3_packed_bias_floats(int cout);
+
+/* Pack nn.Conv2d(k=3) parameters (weight OIHW [cout][cin][3][3], bias [cout] or NULL)
+ * into the MFMA operand image read by sr_conv3x3_f32.
+ *   The cin reference channels are a first segment of `first_seg` channels followed by
+ *   (cin-first_seg)/seg segments of `seg` channels (seg = 0: none).  In the CB8 source
+ *   every segment starts on a multiple of 8 channels: this is where the dense block's
+ *   concat order (x, x1..x4; rrdbnet_arch.py:33-37) meets the padded concat buffer.
+ *   cin_pad = roundup8(first_seg) + nseg*roundup8(seg) is returned by sr_conv3x3_cin_pad.
+ *   mode 0 : forward weights.
+ *   mode 1 : data-gradient weights (roles of cin/cout swapped, taps flipped): the
+ *            packed image convolves dY (cout channels, padded to 8) into dX (cin_pad
+ *            channels, laid out like the forward source); bias is ignored. */
+int sr_conv3x3_cin_pad(int cin, int first_seg, int seg);
+int sr_conv3x3_pack_f32(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg, int mode,
+                        float* wpacked, float* bpacked, void* stream);
+
+typedef struct sr_conv3x3_desc {
+  const float* in;        /* CB8 source (channel slice allowed) */
+  int64_t in_img_stride;  /* floats between images of `in` */
+  int cin_pad;            /* input channels read (multiple of 8) */
+  int cin_real;           /* reference input channels (accounting only; 0 = cin_pad) */
+  int in_h, in_w;         /* source spatial size; output is (in_h, in_w) or 2x when upsample */
+  int upsample;           /* 1: source is nearest-x2 upsampled on the fly
+                             (F.interpolate(scale_factor=2, mode='nearest'), rrdbnet_arch.py:116-117) */
+  const float* wpacked;   /* from sr_conv3x3_pack_f32 */
+  const float* bpacked;   /* may be NULL (no bias) */
+  int cout;               /* real output channels */
+  float* out;             /* CB8 destination (channel slice allowed), or NCHW when out_nchw */
+  int64_t out_img_stride;
+  int out_nchw;           /* 1: write plain NCHW [N][cout][H][W] (cout <= 4), used by conv_last */
+  int n;                  /* batch */
+  float act_slope;        /* LeakyReLU negative slope applied to conv+bias; 1.0f = none */
+  float alpha;            /* out = alpha*act(conv+bias) + beta1*res1 + beta2*res2 */
+  const float* res1; int64_t res1_img_stride; float beta1;  /* CB8, same shape as out; NULL = none */
+  const float* res2; int64_t res2_img_stride; float beta2;
+  int accumulate;         /* 1: out += result (dgrad accumulation into a concat-gradient buffer) */
+  const float* mask_src;  /* optional CB8 tensor of mask_cbn channel blocks: where mask_src <= 0 the
+                             final value is multiplied by mask_slope — LeakyReLU backward fused on
+                             the channel blocks [mask_cb0, mask_cb0+mask_cbn) of out (block 0 of
+                             mask_src pairs with block mask_cb0 of out) */
+  int64_t mask_img_stride; int mask_cb0, mask_cbn; float mask_slope;
+} sr_conv3x3_desc;
+
+/* Fused 3x3 / stride 1 / pad 1 convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d + LeakyReLU + cat + residual scale-add of
+ * ResidualDenseBlock.forward (rrdbnet_arch.py:32-39), RRDB.forward (:58-63) and the
+ * trunk/head convs of RRDBNet.forward (:112-118). */
+int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream);
+
+/* ------------------------------------------------------- whole generator ---- */
+
+typedef struct sr_rrdbnet_cfg {
+  int num_in_ch, num_out_ch, scale, num_feat, num_block, num_grow_ch; /* RRDBNet.__init__, rrdbnet_arch.py:87 */
+} sr_rrdbnet_cfg;
+
+/* Number of parameter tensors (= len(state_dict), 702 for the 23-block net) in
+ * state_dict order: conv_first.{weight,bias}, body.{i}.rdb{1,2,3}.conv{1..5}.{weight,bias},
+ * conv_body, conv_up1, conv_up2, conv_hr, conv_last (rrdbnet_arch.py:94-101). */
+int sr_rrdbnet_num_params(const sr_rrdbnet_cfg* cfg);
+/* Bytes of the packed-parameter blob and of the inference workspace for a
+ * [n][num_in_ch][h][w] input (h, w = spatial size of the tensor given to forward). */
+size_t sr_rrdbnet_packed_bytes(const sr_rrdbnet_cfg* cfg);
+size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+/* Pack all parameters.  host_params: HOST array of sr_rrdbnet_num_params() DEVICE pointers. */
+int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_params, float* packed, void* stream);
+/* y = RRDBNet.forward(x)  (rrdbnet_arch.py:105-119); x NCHW [n][num_in_ch][h][w] fp32,
+ * y NCHW [n][num_out_ch][4h/s'][4w/s'] where s' = 1, 2, 4 for scale 4, 2, 1. */
+int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h,
+                           int w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------ measurement ---- */
+
+/* Opt-in per-launch timing used by bench.py's roofline line: between sr_profile_start and
+ * sr_profile_stop every conv launch issued by the calling thread is bracketed by HIP events
+ * recorded on the launch's own stream.  sr_profile_stop synchronises on those events only. */
+typedef struct sr_launch_record {
+  int32_t kernel_id;          /* index for sr_kernel_name */
+  int32_t cin, cout, n, h, w; /* real channels, batch, OUTPUT spatial size */
+  double flops;               /* algorithmic: 2*9*cin*cout*n*h*w */
+  double bytes;               /* algorithmic HBM bytes: source read once + destination written once
+                                 + residual / accumulate / mask reads */
+  float ms;                   /* event-to-event duration of this launch */
+} sr_launch_record;
+int sr_profile_start(int max_records);
+int sr_profile_stop(sr_launch_record* out, int capacity, int* count);
+/* Device symbol substring of a kernel id (matches the rocprofv3 kernel-trace name). */
+const char* sr_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_HIP_H */
