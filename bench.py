@@ -30,16 +30,37 @@ PEAK_HBM_GBS = 8000.0
 FLOPS_PER_IMAGE = 5.8743e11
 
 
+def usable_cores():
+    """Cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU box shows 256
+    CPUs but grants a 16-core quota; 256 oneDNN threads on 16 cores would measure the scheduler."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline():
     """Oracle (CPU restatement of the reference, PyTorch CPU fp32) on this host's cores, bounded sample."""
     from image_restoration_amd.utils import synth
     from oracle import rrdbnet_ref as R
     sd = {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
     x = torch.from_numpy(synth.uniform_input(1234, (2, 3, TILE, TILE)))
     with torch.no_grad():

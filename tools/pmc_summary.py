@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc counter_collection.csv files per kernel name (mean per dispatch)."""
+import csv
+import collections
+import sys
+
+
+def summarise(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = row['Kernel_Name']
+            agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
+    return agg
+
+
+if __name__ == '__main__':
+    for p in sys.argv[1:]:
+        print('#', p)
+        for k, cs in summarise(p).items():
+            if 'conv3x3' not in k and 'wgrad' not in k and 'sr_' not in k:
+                continue
+            short = k.split('(')[0][-60:] if 'anonymous' not in k else k[k.index('::') + 2:k.index('>(') + 1]
+            print(short, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
