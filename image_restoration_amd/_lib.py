@@ -25,9 +25,19 @@ class ConvDesc(C.Structure):
         ('out', C.c_void_p), ('out_img_stride', C.c_int64), ('out_nchw', C.c_int), ('n', C.c_int),
         ('act_slope', C.c_float), ('alpha', C.c_float),
         ('res1', C.c_void_p), ('res1_img_stride', C.c_int64), ('beta1', C.c_float),
-        ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float),
+        ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float), ('res_cbn', C.c_int),
         ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
         ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """struct sr_conv3x3_wgrad_desc (include/sr_hip.h)."""
+    _fields_ = [
+        ('x', C.c_void_p), ('x_img_stride', C.c_int64), ('cin_pad', C.c_int), ('in_h', C.c_int), ('in_w', C.c_int),
+        ('upsample', C.c_int), ('dy', C.c_void_p), ('dy_img_stride', C.c_int64), ('cout', C.c_int), ('cin', C.c_int),
+        ('first_seg', C.c_int), ('seg', C.c_int), ('n', C.c_int), ('scale', C.c_float), ('dweight', C.c_void_p),
+        ('dbias', C.c_void_p), ('accumulate', C.c_int), ('slab', C.c_void_p), ('slab_bytes', C.c_size_t),
     ]
 
 
@@ -43,20 +53,35 @@ SIGNATURES = {
     'sr_last_error': (C.c_char_p, []),
     'sr_nchw_to_cb8_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int64, C.c_void_p]),
-    'sr_cb8_to_nchw_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+    'sr_cb8_to_nchw_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),
+    'sr_upsample2x_bwd_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_cb8_axpby_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_conv3x3_packed_weight_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'sr_conv3x3_packed_bias_floats': (C.c_size_t, [C.c_int]),
     'sr_conv3x3_cin_pad': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_pack_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_conv3x3_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'sr_conv3x3_wgrad_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'sr_conv3x3_wgrad_f32': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'sr_rrdbnet_num_params': (C.c_int, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_packed_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_pack_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     'sr_rrdbnet_forward_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_rrdbnet_saved_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_backward_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_packed_dgrad_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
+    'sr_rrdbnet_pack_dgrad_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'sr_rrdbnet_forward_train_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_rrdbnet_backward_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
 }
 
 

@@ -99,6 +99,29 @@ class RRDBNet(nn.Module):
         self._packed_key = key
         return self._packed
 
+    def _ensure_packed_dgrad(self, lib, cfg, stream):
+        """Transposed/flipped weight images for the data-gradient convs, cached per parameter version."""
+        params = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in params[0::2])
+        if getattr(self, '_packed_dg', None) is not None and key == self._packed_dg_key:
+            return self._packed_dg
+        dev = params[0].device
+        nbytes = lib.sr_rrdbnet_packed_dgrad_bytes(C.byref(cfg))
+        if getattr(self, '_packed_dg', None) is None or self._packed_dg.numel() != nbytes or self._packed_dg.device != dev:
+            self._packed_dg = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        _lib.check(lib.sr_rrdbnet_pack_dgrad_f32(C.byref(cfg), ptrs, self._packed_dg.data_ptr(), stream),
+                   'sr_rrdbnet_pack_dgrad_f32')
+        self._packed_dg_key = key
+        return self._packed_dg
+
+    def _bwd_workspace(self, nbytes, dev):
+        ws = getattr(self, '_bwd_ws', None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._bwd_ws = ws
+        return ws
+
     def _workspace(self, lib, cfg, n, h, w, dev):
         nbytes = lib.sr_rrdbnet_workspace_bytes(C.byref(cfg), n, h, w)
         if nbytes == 0:

@@ -44,6 +44,7 @@ struct ConvParams {
   int H, W;         // output spatial size
   int tiles_x, tiles_y;
   int mask_cb0, mask_cb1;
+  int res_cb1;      // residuals apply to destination blocks [0, res_cb1)
   float slope, alpha, beta1, beta2, mask_slope;
   int accumulate;
 };
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         v *= p.alpha;
         const long long off = (cb * HW + pixoff) * 8 + h * 4;
-        if (p.res1) v += p.beta1 * *(const f32x4*)(p.res1 + (long long)n * p.res1_ns + off);
-        if (p.res2) v += p.beta2 * *(const f32x4*)(p.res2 + (long long)n * p.res2_ns + off);
+        if (p.res1 && cb < p.res_cb1) v += p.beta1 * *(const f32x4*)(p.res1 + (long long)n * p.res1_ns + off);
+        if (p.res2 && cb < p.res_cb1) v += p.beta2 * *(const f32x4*)(p.res2 + (long long)n * p.res2_ns + off);
         if constexpr (NCHW_OUT) {
           if (h == 0 && cb == 0) {
             float* o = p.out + (long long)n * p.out_ns + pixoff;
@@ -299,6 +300,7 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   p.in_w = d->in_w;
   p.H = d->upsample ? 2 * d->in_h : d->in_h;
   p.W = d->upsample ? 2 * d->in_w : d->in_w;
+  p.res_cb1 = d->res_cbn > 0 ? d->res_cbn : (1 << 30);
   p.mask_cb0 = d->mask_cb0;
   p.mask_cb1 = d->mask_cb0 + d->mask_cbn;
   p.slope = d->act_slope;

@@ -40,16 +40,22 @@ __global__ void nchw_to_cb8_kernel(const float* __restrict__ src, float* __restr
   o[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// One thread per destination element of [N][C][H*u][W*u]; u = 1 is the plain conversion, u > 1 the
+// inverse of the pixel_unshuffle channel order  c_cb8 = (c*u + iy)*u + ix.
 __global__ void cb8_to_nchw_kernel(const float* __restrict__ src, long long src_ns, float* __restrict__ dst, int C, int H,
-                                   int W, long long total) {
+                                   int W, int u, long long total) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int HW = H * W;
-  const int pix = (int)(i % HW);
-  long long r = i / HW;
+  const int SW = W * u, SH = H * u;
+  const int sx = (int)(i % SW);
+  long long r = i / SW;
+  const int sy = (int)(r % SH);
+  r /= SH;
   const int c = (int)(r % C);
   const int n = (int)(r / C);
-  dst[i] = src[n * src_ns + ((long long)(c >> 3) * HW + pix) * 8 + (c & 7)];
+  const int cc = (c * u + sy % u) * u + sx % u;
+  const long long pix = (long long)(sy / u) * W + sx / u;
+  dst[i] = src[n * src_ns + ((long long)(cc >> 3) * H * W + pix) * 8 + (cc & 7)];
 }
 
 // mode 0: thread per (co, ci, tap) of the OIHW weight, scattered into the (pre-zeroed) image
@@ -104,12 +110,13 @@ extern "C" int sr_nchw_to_cb8_f32(const float* src, float* dst, int N, int C, in
 }
 
 extern "C" int sr_cb8_to_nchw_f32(const float* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W,
-                                  void* stream_) {
+                                  int shuffle, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "sr_cb8_to_nchw_f32: bad argument");
-  const long long total = (long long)N * C * H * W;
+  SR_CHECK_ARG(shuffle == 1 || shuffle == 2 || shuffle == 4, "sr_cb8_to_nchw_f32: shuffle must be 1, 2 or 4");
+  const long long total = (long long)N * C * H * W * shuffle * shuffle;
   hipLaunchKernelGGL(cb8_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
-                     (long long)src_img_stride, dst, C, H, W, total);
+                     (long long)src_img_stride, dst, C, H, W, shuffle, total);
   SR_CHECK_LAUNCH("cb8_to_nchw");
   return SR_OK;
 }
@@ -150,5 +157,84 @@ extern "C" int sr_conv3x3_pack_f32(const float* weight, const float* bias, int c
     hipLaunchKernelGGL(pack_b_kernel, dim3((cp + 255) / 256), dim3(256), 0, stream, bias, cout, cp, bpacked);
     SR_CHECK_LAUNCH("pack_b");
   }
+  return SR_OK;
+}
+
+// ---- small HBM-bound helpers of the backward pass -------------------------------------------------
+namespace {
+
+// Backward of F.interpolate(scale_factor=2, mode='nearest') (rrdbnet_arch.py:116-117): every source pixel
+// fed a 2x2 block, so its gradient is the 2x2 sum; optionally followed by the LeakyReLU backward of the
+// activation that produced the source (mask tensor has the destination's shape).
+// One thread per destination float4 (half a pixel-block).
+__global__ void up2x_bwd_kernel(const float* __restrict__ g, long long g_ns, float* __restrict__ dst, long long dst_ns,
+                                const float* __restrict__ mask, long long mask_ns, float slope, int cblocks, int h, int w,
+                                long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int x = (int)(r % w);
+  r /= w;
+  const int y = (int)(r % h);
+  r /= h;
+  const int cb = (int)(r % cblocks);
+  const int n = (int)(r / cblocks);
+  const int W2 = 2 * w;
+  const float* s = g + n * g_ns + (((long long)cb * 2 * h + 2 * y) * W2 + 2 * x) * 8 + half * 4;
+  const float4 a = *(const float4*)s, b = *(const float4*)(s + 8), c = *(const float4*)(s + (long long)W2 * 8),
+               d = *(const float4*)(s + (long long)W2 * 8 + 8);
+  float4 v = make_float4(a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w);
+  const long long off = (((long long)cb * h + y) * w + x) * 8 + half * 4;
+  if (mask) {
+    const float4 m = *(const float4*)(mask + n * mask_ns + off);
+    v.x = m.x > 0.f ? v.x : v.x * slope;
+    v.y = m.y > 0.f ? v.y : v.y * slope;
+    v.z = m.z > 0.f ? v.z : v.z * slope;
+    v.w = m.w > 0.f ? v.w : v.w * slope;
+  }
+  *(float4*)(dst + n * dst_ns + off) = v;
+}
+
+// dst = a*dst + b*src on CB8 windows (float4 granularity).
+__global__ void cb8_axpby_kernel(float* __restrict__ dst, long long dst_ns, const float* __restrict__ src,
+                                 long long src_ns, float a, float b, long long per_img4, long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long n = i / per_img4, o = (i % per_img4) * 4;
+  float4* d = (float4*)(dst + n * dst_ns + o);
+  const float4 s = *(const float4*)(src + n * src_ns + o);
+  float4 v = *d;
+  v.x = a * v.x + b * s.x;
+  v.y = a * v.y + b * s.y;
+  v.z = a * v.z + b * s.z;
+  v.w = a * v.w + b * s.w;
+  *d = v;
+}
+
+}  // namespace
+
+extern "C" int sr_upsample2x_bwd_f32(const float* g, int64_t g_img_stride, float* dst, int64_t dst_img_stride,
+                                     const float* mask, int64_t mask_img_stride, float mask_slope, int n, int cblocks,
+                                     int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_upsample2x_bwd_f32: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 2;
+  hipLaunchKernelGGL(up2x_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g,
+                     (long long)g_img_stride, dst, (long long)dst_img_stride, mask, (long long)mask_img_stride,
+                     mask_slope, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("up2x_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_cb8_axpby_f32(float* dst, int64_t dst_img_stride, const float* src, int64_t src_img_stride, float a,
+                                float b, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(dst && src && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb8_axpby_f32: bad argument");
+  const long long per_img4 = (long long)cblocks * h * w * 2;
+  const long long total = per_img4 * n;
+  hipLaunchKernelGGL(cb8_axpby_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dst,
+                     (long long)dst_img_stride, src, (long long)src_img_stride, a, b, per_img4, total);
+  SR_CHECK_LAUNCH("cb8_axpby");
   return SR_OK;
 }

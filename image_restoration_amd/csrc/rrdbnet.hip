@@ -1,16 +1,23 @@
-// Whole-generator host driver: RRDBNet.forward (rrdbnet_arch.py:105-119) as a fixed
-// sequence of fused conv launches on one stream — no allocation, no sync, graph-capturable.
+// Whole-generator host drivers: RRDBNet.forward (rrdbnet_arch.py:105-119) and its autograd
+// backward as fixed sequences of fused launches on one stream — no allocation, no sync,
+// graph-capturable.
 //
 // HBM plan for an [n][cin][h][w] trunk input (h, w after the optional pixel_unshuffle):
-//   xin   CB8 [n][cinb][h][w][8]          network input
-//   feat0 CB8 [n][nfb ][h][w][8]          conv_first output (kept for feat + body_feat, :114)
-//   cat[4] CB8 [n][nfb+4*gcb][h][w][8]    dense-block concat buffers: block k of an RDB writes
-//                                         its growth channels straight behind x, so torch.cat
-//                                         (:34-37) never exists.  Four buffers rotate: the three
-//                                         RDBs of an RRDB + the next RRDB's input.
-//   trunk CB8 [n][nfb][h][w][8], up1 [.. 2h 2w], up2 / hr [.. 4h 4w]
-// The RDB residual (x5*0.2 + x, :39) and the RRDB residual (out*0.2 + x, :63) are epilogues
-// of conv5:  rdb3.conv5 writes 0.04*conv + 0.2*x_rdb3 + x_rrdb.
+//   xin    CB8 [n][cinb][h][w][8]          network input
+//   feat0  CB8 [n][nfb ][h][w][8]          conv_first output (kept for feat + body_feat, :114)
+//   cat[q] CB8 [n][nfb+4*gcb][h][w][8]     dense-block concat buffers: conv_k of an RDB writes its
+//                                          growth channels straight behind x, so torch.cat (:34-37)
+//                                          never exists.  Inference rotates 4 buffers (the three
+//                                          RDBs of an RRDB + the next RRDB's input); training keeps
+//                                          one per RDB (3*num_block+1) because backward re-reads them.
+//   trunk  CB8 [n][nfb][h][w][8], up1 [.. 2h 2w], up2 / hr [.. 4h 4w]
+// The RDB residual (x5*0.2 + x, :39) and the RRDB residual (out*0.2 + x, :63) are epilogues of
+// conv5:  rdb3.conv5 writes 0.04*conv + 0.2*x_rdb3 + x_rrdb.
+//
+// Backward mirrors it with a rotating set of 4 concat-GRADIENT buffers G: conv5's data gradient
+// writes all 192 channels of G (plus the residual branch on the first 64), conv4..conv1 accumulate
+// into the channels below their own slice, and the LeakyReLU backward of x_{k-1} is applied in the
+// epilogue of the pass that completes its gradient.  Weight gradients use sr_conv3x3_wgrad_f32.
 #include <vector>
 
 #include "sr_internal.h"
@@ -19,13 +26,14 @@ namespace {
 
 struct ConvPlan {
   int cout, cin, first_seg, seg, cin_pad;
-  size_t w_off, b_off;  // float offsets in the packed blob
+  size_t w_off, b_off;  // float offsets in the packed (forward) blob
+  size_t dg_off;        // float offset in the packed data-gradient blob
 };
 
 struct NetPlan {
   int nfp, gcp, cin0, cin0_pad, unshuffle;
   std::vector<ConvPlan> convs;  // state_dict order
-  size_t packed_floats;
+  size_t packed_floats, dgrad_floats;
 };
 
 int r8(int v) { return (v + 7) / 8 * 8; }
@@ -39,7 +47,7 @@ bool make_plan(const sr_rrdbnet_cfg* c, NetPlan* P) {
   P->cin0_pad = r8(P->cin0);
   P->nfp = r8(c->num_feat);
   P->gcp = r8(c->num_grow_ch);
-  size_t off = 0;
+  size_t off = 0, dg = 0;
   auto add = [&](int cout, int cin, int first_seg, int seg) {
     ConvPlan cp;
     cp.cout = cout;
@@ -51,6 +59,8 @@ bool make_plan(const sr_rrdbnet_cfg* c, NetPlan* P) {
     off += sr::align_up(sr_conv3x3_packed_weight_floats(cout, cp.cin_pad), 64);
     cp.b_off = off;
     off += sr::align_up(sr_conv3x3_packed_bias_floats(cout), 64);
+    cp.dg_off = dg;
+    dg += sr::align_up(sr_conv3x3_packed_weight_floats(cp.cin_pad, r8(cout)), 64);
     P->convs.push_back(cp);
   };
   const int nf = c->num_feat, gc = c->num_grow_ch;
@@ -60,97 +70,93 @@ bool make_plan(const sr_rrdbnet_cfg* c, NetPlan* P) {
       for (int k = 1; k <= 4; ++k) add(gc, nf + (k - 1) * gc, nf, gc);  // conv1..conv4 (:21-24)
       add(nf, nf + 4 * gc, nf, gc);                                     // conv5 (:25)
     }
-  add(nf, nf, nf, 0);              // conv_body
-  add(nf, nf, nf, 0);              // conv_up1
-  add(nf, nf, nf, 0);              // conv_up2
-  add(nf, nf, nf, 0);              // conv_hr
-  add(c->num_out_ch, nf, nf, 0);   // conv_last
+  add(nf, nf, nf, 0);             // conv_body
+  add(nf, nf, nf, 0);             // conv_up1
+  add(nf, nf, nf, 0);             // conv_up2
+  add(nf, nf, nf, 0);             // conv_hr
+  add(c->num_out_ch, nf, nf, 0);  // conv_last
   P->packed_floats = off;
+  P->dgrad_floats = dg;
   return true;
 }
 
-struct Workspace {
-  float *xin, *feat0, *cat[4], *trunk, *up1, *up2, *hr, *last;
-  size_t bytes;
-};
-
-Workspace carve(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int w, char* base) {
-  Workspace W;
+struct Carver {
+  char* base;
   size_t off = 0;
-  const size_t hw = (size_t)h * w;
-  auto take = [&](size_t floats) {
+  float* take(size_t floats) {
     float* p = (float*)(base + off);
     off += sr::align_up(floats * sizeof(float), 256);
     return p;
-  };
+  }
+};
+
+// Forward workspace.  train = false: 4 rotating concat buffers; train = true: one per RDB + 1.
+struct FwdSpace {
+  float *xin, *feat0, *trunk, *up1, *up2, *hr, *last;
+  std::vector<float*> cat;
+  size_t bytes;
+};
+
+FwdSpace carve_fwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int w, char* base, bool train) {
+  FwdSpace W;
+  Carver cv{base};
+  const size_t hw = (size_t)h * w;
   const int ctot = P.nfp + 4 * P.gcp;
-  W.xin = take((size_t)n * P.cin0_pad * hw);
-  W.feat0 = take((size_t)n * P.nfp * hw);
-  for (int i = 0; i < 4; ++i) W.cat[i] = take((size_t)n * ctot * hw);
-  W.trunk = take((size_t)n * P.nfp * hw);
-  W.up1 = take((size_t)n * P.nfp * hw * 4);
-  W.up2 = take((size_t)n * P.nfp * hw * 16);
-  W.hr = take((size_t)n * P.nfp * hw * 16);
-  W.last = c->num_out_ch > 4 ? take((size_t)n * r8(c->num_out_ch) * hw * 16) : nullptr;
-  W.bytes = off;
+  W.xin = cv.take((size_t)n * P.cin0_pad * hw);
+  W.feat0 = cv.take((size_t)n * P.nfp * hw);
+  const int ncat = train ? 3 * c->num_block + 1 : 4;
+  for (int i = 0; i < ncat; ++i) W.cat.push_back(cv.take((size_t)n * ctot * hw));
+  W.trunk = cv.take((size_t)n * P.nfp * hw);
+  W.up1 = cv.take((size_t)n * P.nfp * hw * 4);
+  W.up2 = cv.take((size_t)n * P.nfp * hw * 16);
+  W.hr = cv.take((size_t)n * P.nfp * hw * 16);
+  W.last = c->num_out_ch > 4 ? cv.take((size_t)n * r8(c->num_out_ch) * hw * 16) : nullptr;
+  W.bytes = cv.off;
   return W;
 }
 
-}  // namespace
+struct BwdSpace {
+  float *dyl, *a16, *b16, *a4, *b4, *dtrunk, *g[4], *dxin;
+  void* slab;
+  size_t slab_bytes, bytes;
+};
 
-extern "C" int sr_rrdbnet_num_params(const sr_rrdbnet_cfg* cfg) {
-  NetPlan P;
-  if (!make_plan(cfg, &P)) return SR_EINVAL;
-  return 2 * (int)P.convs.size();
+BwdSpace carve_bwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int w, char* base) {
+  BwdSpace B;
+  Carver cv{base};
+  const size_t hw = (size_t)h * w;
+  const int ctot = P.nfp + 4 * P.gcp;
+  B.dyl = cv.take((size_t)n * r8(c->num_out_ch) * hw * 16);
+  B.a16 = cv.take((size_t)n * P.nfp * hw * 16);
+  B.b16 = cv.take((size_t)n * P.nfp * hw * 16);
+  B.a4 = cv.take((size_t)n * P.nfp * hw * 4);
+  B.b4 = cv.take((size_t)n * P.nfp * hw * 4);
+  B.dtrunk = cv.take((size_t)n * P.nfp * hw);
+  for (int i = 0; i < 4; ++i) B.g[i] = cv.take((size_t)n * ctot * hw);
+  B.dxin = cv.take((size_t)n * P.cin0_pad * hw);
+  B.slab_bytes = sr_conv3x3_wgrad_slab_bytes(n, 4 * h, 4 * w);
+  B.slab = cv.take(B.slab_bytes / sizeof(float));
+  B.bytes = cv.off;
+  return B;
 }
 
-extern "C" size_t sr_rrdbnet_packed_bytes(const sr_rrdbnet_cfg* cfg) {
+int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h_in, int w_in,
+                 void* workspace, size_t workspace_bytes, hipStream_t stream, bool train) {
   NetPlan P;
-  if (!make_plan(cfg, &P)) return 0;
-  return P.packed_floats * sizeof(float);
-}
-
-extern "C" size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
-  NetPlan P;
-  if (!make_plan(cfg, &P) || n <= 0 || h <= 0 || w <= 0) return 0;
-  if (h % P.unshuffle || w % P.unshuffle) return 0;
-  return carve(cfg, P, n, h / P.unshuffle, w / P.unshuffle, nullptr).bytes;
-}
-
-extern "C" int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_params, float* packed,
-                                   void* stream) {
-  NetPlan P;
-  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_pack_f32: bad config");
-  SR_CHECK_ARG(host_params && packed, "sr_rrdbnet_pack_f32: null argument");
-  for (size_t i = 0; i < P.convs.size(); ++i) {
-    const ConvPlan& cp = P.convs[i];
-    SR_CHECK_ARG(host_params[2 * i] && host_params[2 * i + 1], "sr_rrdbnet_pack_f32: null parameter %zu", i);
-    int rc = sr_conv3x3_pack_f32(host_params[2 * i], host_params[2 * i + 1], cp.cout, cp.cin, cp.first_seg, cp.seg, 0,
-                                 packed + cp.w_off, packed + cp.b_off, stream);
-    if (rc) return rc;
-  }
-  return SR_OK;
-}
-
-extern "C" int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n,
-                                      int h_in, int w_in, void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  NetPlan P;
-  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_forward_f32: bad config");
-  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "sr_rrdbnet_forward_f32: bad argument");
+  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_forward: bad config");
+  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "sr_rrdbnet_forward: bad argument");
   // pixel_unshuffle divisibility: the reference asserts (arch_util.py:197)
   SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0,
-               "sr_rrdbnet_forward_f32: %dx%d input is not divisible by the pixel_unshuffle factor %d", h_in, w_in,
+               "sr_rrdbnet_forward: %dx%d input is not divisible by the pixel_unshuffle factor %d", h_in, w_in,
                P.unshuffle);
-  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "sr_rrdbnet_forward_f32: workspace must be 256-byte aligned");
+  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "sr_rrdbnet_forward: workspace must be 256-byte aligned");
   const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
-  const Workspace W = carve(cfg, P, n, h, w, (char*)workspace);
+  const FwdSpace W = carve_fwd(cfg, P, n, h, w, (char*)workspace, train);
   if (W.bytes > workspace_bytes) {
-    sr::set_error("sr_rrdbnet_forward_f32: workspace %zu B < required %zu B", workspace_bytes, W.bytes);
+    sr::set_error("sr_rrdbnet_forward: workspace %zu B < required %zu B", workspace_bytes, W.bytes);
     return SR_ENOSPACE;
   }
   const long long hw = (long long)h * w;
-  const int nf = cfg->num_feat, gc = cfg->num_grow_ch;
   const int ctot = P.nfp + 4 * P.gcp;
   const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;
   int rc = sr_nchw_to_cb8_f32(x, W.xin, n, cfg->num_in_ch, h, w, P.unshuffle, P.cin0_pad / 8,
@@ -187,28 +193,34 @@ extern "C" int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* pa
     d.beta2 = b2;
     return sr_conv3x3_f32(&d, stream);
   };
+  auto cat = [&](int q) { return W.cat[train ? q : (q & 3)]; };
 
-  // conv_first (:112): no activation.  With blocks, it lands in the first concat buffer and is
-  // copied to feat0 for the long skip; without blocks it is the trunk itself.
-  float* first_dst = cfg->num_block > 0 ? W.cat[0] : W.feat0;
-  const long long first_ns = cfg->num_block > 0 ? cat_ns : feat_ns;
+  // conv_first (:112): no activation.  With blocks it lands in the first concat buffer; inference copies it to
+  // feat0 for the long skip (the buffer is recycled), training reads it in place.
+  const bool blocks = cfg->num_block > 0;
+  float* first_dst = blocks ? cat(0) : W.feat0;
+  const long long first_ns = blocks ? cat_ns : feat_ns;
   rc = conv(W.xin, (long long)P.cin0_pad * hw, h, w, 0, first_dst, first_ns, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
   if (rc) return rc;
-  if (cfg->num_block > 0) {
-    hipError_t e = hipMemcpy2DAsync(W.feat0, feat_ns * sizeof(float), W.cat[0], cat_ns * sizeof(float),
+  const float* skip = W.feat0;
+  long long skip_ns = feat_ns;
+  if (blocks && train) {
+    skip = cat(0);
+    skip_ns = cat_ns;
+  } else if (blocks) {
+    hipError_t e = hipMemcpy2DAsync(W.feat0, feat_ns * sizeof(float), cat(0), cat_ns * sizeof(float),
                                     feat_ns * sizeof(float), n, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) {
-      sr::set_error("sr_rrdbnet_forward_f32: feat0 copy: %s", hipGetErrorString(e));
+      sr::set_error("sr_rrdbnet_forward: feat0 copy: %s", hipGetErrorString(e));
       return SR_ELAUNCH;
     }
   }
   // body (:113): 3 RDBs per RRDB
-  int cur = 0;
   for (int b = 0; b < cfg->num_block; ++b) {
-    const float* x_rrdb = W.cat[cur];
+    const float* x_rrdb = cat(3 * b);
     for (int r = 0; r < 3; ++r) {
-      float* buf = W.cat[(cur + r) & 3];
-      float* nxt = W.cat[(cur + r + 1) & 3];
+      float* buf = cat(3 * b + r);
+      float* nxt = cat(3 * b + r + 1);
       for (int k = 1; k <= 4; ++k) {  // x_k = lrelu(conv_k(cat(x, x1..x_{k-1})))  (:33-36)
         rc = conv(buf, cat_ns, h, w, 0, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, cat_ns, 0.2f, 1.f, nullptr, 0,
                   0.f, nullptr, 0, 0.f, 0);
@@ -220,12 +232,11 @@ extern "C" int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* pa
         rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f, 0);
       if (rc) return rc;
     }
-    cur = (cur + 3) & 3;
   }
   // feat = feat + conv_body(body(feat))  (:113-114)
-  const float* body_out = cfg->num_block > 0 ? W.cat[cur] : W.feat0;
-  const long long body_ns = cfg->num_block > 0 ? cat_ns : feat_ns;
-  rc = conv(body_out, body_ns, h, w, 0, W.trunk, feat_ns, 1.f, 1.f, W.feat0, feat_ns, 1.f, nullptr, 0, 0.f, 0);
+  const float* body_out = blocks ? cat(3 * cfg->num_block) : W.feat0;
+  const long long body_ns = blocks ? cat_ns : feat_ns;
+  rc = conv(body_out, body_ns, h, w, 0, W.trunk, feat_ns, 1.f, 1.f, skip, skip_ns, 1.f, nullptr, 0, 0.f, 0);
   if (rc) return rc;
   // head (:116-118)
   rc = conv(W.trunk, feat_ns, h, w, 1, W.up1, feat_ns * 4, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
@@ -243,10 +254,268 @@ extern "C" int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* pa
     const long long last_ns = (long long)r8(cfg->num_out_ch) * ohw;
     rc = conv(W.hr, feat_ns * 16, 4 * h, 4 * w, 0, W.last, last_ns, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
     if (rc) return rc;
-    rc = sr_cb8_to_nchw_f32(W.last, last_ns, y, n, cfg->num_out_ch, 4 * h, 4 * w, stream);
+    rc = sr_cb8_to_nchw_f32(W.last, last_ns, y, n, cfg->num_out_ch, 4 * h, 4 * w, 1, stream);
     if (rc) return rc;
   }
-  (void)nf;
-  (void)gc;
+  return SR_OK;
+}
+
+size_t space_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w, int which) {
+  NetPlan P;
+  if (!make_plan(cfg, &P) || n <= 0 || h <= 0 || w <= 0) return 0;
+  if (h % P.unshuffle || w % P.unshuffle) return 0;
+  h /= P.unshuffle;
+  w /= P.unshuffle;
+  if (which == 2) return carve_bwd(cfg, P, n, h, w, nullptr).bytes;
+  return carve_fwd(cfg, P, n, h, w, nullptr, which == 1).bytes;
+}
+
+}  // namespace
+
+extern "C" int sr_rrdbnet_num_params(const sr_rrdbnet_cfg* cfg) {
+  NetPlan P;
+  if (!make_plan(cfg, &P)) return SR_EINVAL;
+  return 2 * (int)P.convs.size();
+}
+
+extern "C" size_t sr_rrdbnet_packed_bytes(const sr_rrdbnet_cfg* cfg) {
+  NetPlan P;
+  if (!make_plan(cfg, &P)) return 0;
+  return P.packed_floats * sizeof(float);
+}
+
+extern "C" size_t sr_rrdbnet_packed_dgrad_bytes(const sr_rrdbnet_cfg* cfg) {
+  NetPlan P;
+  if (!make_plan(cfg, &P)) return 0;
+  return P.dgrad_floats * sizeof(float);
+}
+
+extern "C" size_t sr_rrdbnet_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  return space_bytes(cfg, n, h, w, 0);
+}
+extern "C" size_t sr_rrdbnet_saved_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  return space_bytes(cfg, n, h, w, 1);
+}
+extern "C" size_t sr_rrdbnet_backward_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  return space_bytes(cfg, n, h, w, 2);
+}
+
+extern "C" int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_params, float* packed,
+                                   void* stream) {
+  NetPlan P;
+  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_pack_f32: bad config");
+  SR_CHECK_ARG(host_params && packed, "sr_rrdbnet_pack_f32: null argument");
+  for (size_t i = 0; i < P.convs.size(); ++i) {
+    const ConvPlan& cp = P.convs[i];
+    SR_CHECK_ARG(host_params[2 * i] && host_params[2 * i + 1], "sr_rrdbnet_pack_f32: null parameter %zu", i);
+    int rc = sr_conv3x3_pack_f32(host_params[2 * i], host_params[2 * i + 1], cp.cout, cp.cin, cp.first_seg, cp.seg, 0,
+                                 packed + cp.w_off, packed + cp.b_off, stream);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_pack_dgrad_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_params,
+                                         float* packed_dgrad, void* stream) {
+  NetPlan P;
+  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_pack_dgrad_f32: bad config");
+  SR_CHECK_ARG(host_params && packed_dgrad, "sr_rrdbnet_pack_dgrad_f32: null argument");
+  for (size_t i = 0; i < P.convs.size(); ++i) {
+    const ConvPlan& cp = P.convs[i];
+    SR_CHECK_ARG(host_params[2 * i], "sr_rrdbnet_pack_dgrad_f32: null parameter %zu", i);
+    int rc = sr_conv3x3_pack_f32(host_params[2 * i], nullptr, cp.cout, cp.cin, cp.first_seg, cp.seg, 1,
+                                 packed_dgrad + cp.dg_off, nullptr, stream);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n,
+                                      int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_impl(cfg, packed, x, y, n, h, w, workspace, workspace_bytes, (hipStream_t)stream, false);
+}
+
+extern "C" int sr_rrdbnet_forward_train_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y,
+                                            int n, int h, int w, void* saved, size_t saved_bytes, void* stream) {
+  return forward_impl(cfg, packed, x, y, n, h, w, saved, saved_bytes, (hipStream_t)stream, true);
+}
+
+extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad, const void* saved,
+                                       size_t saved_bytes, const float* dy, int n, int h_in, int w_in,
+                                       float* const* host_dparams, float* dx, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NetPlan P;
+  SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_backward_f32: bad config");
+  SR_CHECK_ARG(packed_dgrad && saved && dy && host_dparams && workspace && n > 0, "sr_rrdbnet_backward_f32: bad argument");
+  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "sr_rrdbnet_backward_f32: bad spatial size");
+  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)saved % 256 == 0,
+               "sr_rrdbnet_backward_f32: workspaces must be 256-byte aligned");
+  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  const FwdSpace S = carve_fwd(cfg, P, n, h, w, (char*)saved, true);
+  const BwdSpace B = carve_bwd(cfg, P, n, h, w, (char*)workspace);
+  if (S.bytes > saved_bytes || B.bytes > workspace_bytes) {
+    sr::set_error("sr_rrdbnet_backward_f32: saved %zu/%zu B, workspace %zu/%zu B", saved_bytes, S.bytes,
+                  workspace_bytes, B.bytes);
+    return SR_ENOSPACE;
+  }
+  const long long hw = (long long)h * w;
+  const int nfb = P.nfp / 8, gcb = P.gcp / 8;
+  const int ctot = P.nfp + 4 * P.gcp;
+  const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;
+  const int nconv = (int)P.convs.size();
+  int rc;
+
+  // Data-gradient pass of conv `ci`: out = alpha*dgrad(in) [+ residuals on the first nfb blocks] [accumulated]
+  // [LeakyReLU-backward mask on blocks mask_cb0..].
+  auto dgrad = [&](int ci, const float* in, long long in_ns, int oh, int ow, float* out, long long out_ns, float alpha,
+                   const float* r1, long long r1_ns, float b1, const float* r2, long long r2_ns, float b2, int accumulate,
+                   const float* mask, long long mask_ns, int mask_cb0, int mask_cbn) -> int {
+    const ConvPlan& cp = P.convs[ci];
+    sr_conv3x3_desc d = {};
+    d.in = in;
+    d.in_img_stride = in_ns;
+    d.cin_pad = r8(cp.cout);
+    d.cin_real = cp.cout;
+    d.in_h = oh;
+    d.in_w = ow;
+    d.wpacked = packed_dgrad + cp.dg_off;
+    d.cout = cp.cin_pad;
+    d.out = out;
+    d.out_img_stride = out_ns;
+    d.n = n;
+    d.act_slope = 1.f;
+    d.alpha = alpha;
+    d.res1 = r1;
+    d.res1_img_stride = r1_ns;
+    d.beta1 = b1;
+    d.res2 = r2;
+    d.res2_img_stride = r2_ns;
+    d.beta2 = b2;
+    d.res_cbn = nfb;
+    d.accumulate = accumulate;
+    d.mask_src = mask;
+    d.mask_img_stride = mask_ns;
+    d.mask_cb0 = mask_cb0;
+    d.mask_cbn = mask_cbn;
+    d.mask_slope = 0.2f;
+    return sr_conv3x3_f32(&d, stream);
+  };
+  auto wgrad = [&](int ci, const float* xsrc, long long x_ns, int ih, int iw, int ups, const float* dyp,
+                   long long dy_ns, float scale) -> int {
+    const ConvPlan& cp = P.convs[ci];
+    float* dwp = host_dparams[2 * ci];
+    float* dbp = host_dparams[2 * ci + 1];
+    if (!dwp) return SR_OK;  // parameter does not need a gradient
+    sr_conv3x3_wgrad_desc d = {};
+    d.x = xsrc;
+    d.x_img_stride = x_ns;
+    d.cin_pad = cp.cin_pad;
+    d.in_h = ih;
+    d.in_w = iw;
+    d.upsample = ups;
+    d.dy = dyp;
+    d.dy_img_stride = dy_ns;
+    d.cout = cp.cout;
+    d.cin = cp.cin;
+    d.first_seg = cp.first_seg;
+    d.seg = cp.seg;
+    d.n = n;
+    d.scale = scale;
+    d.dweight = dwp;
+    d.dbias = dbp;
+    d.slab = B.slab;
+    d.slab_bytes = B.slab_bytes;
+    return sr_conv3x3_wgrad_f32(&d, stream);
+  };
+
+  const int i_first = 0, i_body = nconv - 5, i_up1 = nconv - 4, i_up2 = nconv - 3, i_hr = nconv - 2, i_last = nconv - 1;
+  const int ocb = r8(cfg->num_out_ch) / 8;
+  const long long ohw = hw * 16;
+  // dL/dy (NCHW) -> CB8
+  rc = sr_nchw_to_cb8_f32(dy, B.dyl, n, cfg->num_out_ch, 4 * h, 4 * w, 1, ocb, (long long)ocb * 8 * ohw, stream);
+  if (rc) return rc;
+  // conv_last (:118): no activation after it; its input hr = lrelu(conv_hr(..))
+  rc = wgrad(i_last, S.hr, feat_ns * 16, 4 * h, 4 * w, 0, B.dyl, (long long)ocb * 8 * ohw, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_last, B.dyl, (long long)ocb * 8 * ohw, 4 * h, 4 * w, B.a16, feat_ns * 16, 1.f, nullptr, 0, 0.f, nullptr, 0,
+             0.f, 0, S.hr, feat_ns * 16, 0, nfb);  // a16 = dL/d(conv_hr pre-activation)
+  if (rc) return rc;
+  // conv_hr
+  rc = wgrad(i_hr, S.up2, feat_ns * 16, 4 * h, 4 * w, 0, B.a16, feat_ns * 16, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_hr, B.a16, feat_ns * 16, 4 * h, 4 * w, B.b16, feat_ns * 16, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0,
+             S.up2, feat_ns * 16, 0, nfb);  // b16 = dL/d(conv_up2 pre-activation)
+  if (rc) return rc;
+  // conv_up2 reads up1 through the nearest x2 upsample (:117)
+  rc = wgrad(i_up2, S.up1, feat_ns * 4, 2 * h, 2 * w, 1, B.b16, feat_ns * 16, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16, feat_ns * 16, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0,
+             nullptr, 0, 0, 0);  // a16 = dL/d(upsampled up1)
+  if (rc) return rc;
+  rc = sr_upsample2x_bwd_f32(B.a16, feat_ns * 16, B.a4, feat_ns * 4, S.up1, feat_ns * 4, 0.2f, n, nfb, 2 * h, 2 * w,
+                             stream);  // a4 = dL/d(conv_up1 pre-activation)
+  if (rc) return rc;
+  // conv_up1 reads trunk through the upsample (:116)
+  rc = wgrad(i_up1, S.trunk, feat_ns, h, w, 1, B.a4, feat_ns * 4, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_up1, B.a4, feat_ns * 4, 2 * h, 2 * w, B.b4, feat_ns * 4, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0, nullptr,
+             0, 0, 0);
+  if (rc) return rc;
+  rc = sr_upsample2x_bwd_f32(B.b4, feat_ns * 4, B.dtrunk, feat_ns, nullptr, 0, 0.2f, n, nfb, h, w, stream);
+  if (rc) return rc;  // dtrunk = dL/d(feat + body_feat)
+  // conv_body (:113): input = body output
+  const bool blocks = cfg->num_block > 0;
+  const float* body_out = blocks ? S.cat[3 * cfg->num_block] : S.feat0;
+  const long long body_ns = blocks ? cat_ns : feat_ns;
+  rc = wgrad(i_body, body_out, body_ns, h, w, 0, B.dtrunk, feat_ns, 1.f);
+  if (rc) return rc;
+  int gi = 0;  // G buffer holding the gradient wrt the current block output in its first nfb blocks
+  rc = dgrad(i_body, B.dtrunk, feat_ns, h, w, B.g[gi], cat_ns, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0, nullptr, 0, 0, 0);
+  if (rc) return rc;
+  // body, in reverse
+  for (int b = cfg->num_block - 1; b >= 0; --b) {
+    const float* d_rrdb = B.g[gi];  // dL/d(RRDB output)
+    for (int r = 2; r >= 0; --r) {
+      const int q = 3 * b + r;
+      const float* cat = S.cat[q];
+      const float* dout = B.g[gi];
+      float* G = B.g[(gi + 1) & 3];
+      const int c5 = 1 + 5 * q + 4;
+      // out = 0.2*x5 + x; for rdb3 the block output is further scaled by 0.2 into the RRDB output (:39, :63)
+      const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
+      rc = wgrad(c5, cat, cat_ns, h, w, 0, dout, cat_ns, s5);
+      if (rc) return rc;
+      // G[0:192] = s5*dgrad5(dout); G[0:64] += sres*dout (+ dL/d(RRDB out) once the RRDB input is reached);
+      // LeakyReLU backward of x4 on its slice.
+      rc = dgrad(c5, dout, cat_ns, h, w, G, cat_ns, s5, dout, cat_ns, sres, r == 0 ? d_rrdb : nullptr, cat_ns, 1.f, 0,
+                 cat + (long long)(P.nfp + 3 * P.gcp) * hw, cat_ns, nfb + 3 * gcb, gcb);
+      if (rc) return rc;
+      for (int k = 4; k >= 1; --k) {
+        const int ck = 1 + 5 * q + (k - 1);
+        const float* dyk = G + (long long)(P.nfp + (k - 1) * P.gcp) * hw;  // dL/d(conv_k pre-activation)
+        rc = wgrad(ck, cat, cat_ns, h, w, 0, dyk, cat_ns, 1.f);
+        if (rc) return rc;
+        const bool has_mask = k >= 2;  // x_{k-1} is an activation output; x itself is not
+        rc = dgrad(ck, dyk, cat_ns, h, w, G, cat_ns, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 1,
+                   has_mask ? cat + (long long)(P.nfp + (k - 2) * P.gcp) * hw : nullptr, cat_ns, nfb + (k - 2) * gcb,
+                   has_mask ? gcb : 0);
+        if (rc) return rc;
+      }
+      gi = (gi + 1) & 3;
+    }
+  }
+  // dL/d(conv_first output) = gradient through the body + the long skip (:114)
+  rc = sr_cb8_axpby_f32(B.g[gi], cat_ns, B.dtrunk, feat_ns, 1.f, 1.f, n, nfb, h, w, stream);
+  if (rc) return rc;
+  rc = wgrad(i_first, S.xin, (long long)P.cin0_pad * hw, h, w, 0, B.g[gi], cat_ns, 1.f);
+  if (rc) return rc;
+  if (dx) {
+    rc = dgrad(i_first, B.g[gi], cat_ns, h, w, B.dxin, (long long)P.cin0_pad * hw, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f,
+               0, nullptr, 0, 0, 0);
+    if (rc) return rc;
+    rc = sr_cb8_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
+    if (rc) return rc;
+  }
   return SR_OK;
 }

@@ -1,0 +1,384 @@
+// Weight gradient of the fused 3x3 convolution on fp32 MFMA (gfx950).
+//
+// Autograd counterpart of nn.Conv2d's weight/bias gradient on the RRDBNet path
+// (rrdbnet_arch.py:21-25,94-101 through ESRGANModel.optimize_parameters' backward calls,
+// esrgan_model.py:47,68,72):   dW[co][ci][tap] = sum_p dY[co][p] * X[ci][p + tap],   db[co] = sum_p dY[co][p].
+//
+// GEMM view: D[cout][cin] (per tap) += A[cout][k] * B[k][cin] with k = PIXELS, on
+// v_mfma_f32_32x32x2_f32.  One wave owns one (32-cout tile, 32-cin tile) pair for all 9 taps
+// (9 x 16 accumulator registers) and walks pixels; a workgroup is 4 waves = P tile pairs x KS
+// row-splits (P*KS = 4) that share the staged rows.  A workgroup walks DOWN a 32-pixel-wide
+// column strip: per step it consumes R = KS output rows; input rows live in an LDS ring of
+// 2R+2 rows ([34 px][32*IT ch], pixel-major so a lane's operand is one conflict-free
+// ds_read_b32), dY rows in a 2R-row ring ([32 px][32*CT]).  Rows arrive by LDS-DMA
+// (global_load_lds_dwordx4, per-lane source address out of the CB8 planes; halo / ragged /
+// channel padding = the zero line; the head's nearest x2 upsample = src >> 1).
+// Partial sums leave the workgroup once (deterministic slab, no atomics); a second kernel sums
+// the slab over workgroups, applies the scale and scatters to OIHW.
+#include "sr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float g_zero_line_w[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct WgradParams {
+  const float* x;   // forward source activation, CB8
+  const float* dy;  // gradient wrt the conv's (pre-activation) output, CB8
+  float* slab;      // [splits][pairs_in_launch][9][1024]
+  float* bslab;     // [splits][CT][32] or null
+  long long x_ns, dy_ns;
+  int x_h, x_w;     // source spatial size
+  int H, W;         // output spatial size
+  int cin_blocks;   // valid channel blocks of x
+  int cout_blocks;  // valid channel blocks of dy
+  int cin_tile0;    // first 32-channel cin tile of this launch
+  int cout_tile0;   // first 32-channel cout tile of this launch
+  int strips;       // column strips per image = ceil(W/32)
+  int rows_per_wg;  // multiple of R
+  int row_splits;   // ceil(H / rows_per_wg)
+};
+
+__device__ __forceinline__ void glds16w(const float* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// R = output rows per step.  R == KS: the KS waves of a pair split the step's rows;
+// R == 1 (with KS > 1): they split the 16 pixel-pair k-steps of the single row.
+template <int CT, int IT, int R, bool UPS>
+__global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int P = CT * IT, KS = 4 / P;
+  static_assert(R == KS || R == 1, "row split or k-step split");
+  constexpr bool ROWSPLIT = (R == KS);
+  constexpr int SN = ROWSPLIT ? 16 : 16 / KS;  // k-steps per wave per row
+  constexpr int XCH = 32 * IT, YCH = 32 * CT;
+  constexpr int XPIECES = 34 * (XCH / 4);                      // 16-byte pieces of one X row
+  constexpr int XUNITS = (XPIECES + 63) / 64;                  // wave-instructions per X row
+  constexpr int XROWB = XUNITS * 1024;                         // bytes per X ring slot
+  constexpr int YUNITS = (32 * (YCH / 4)) / 64;                // = 4*CT
+  constexpr int YROWB = YUNITS * 1024;
+  constexpr int NXR = 2 * R + 2, NYR = 2 * R;                  // ring depths (rows)
+  constexpr int XRING = NXR * XROWB;
+  constexpr int UNITS_PER_STEP = R * (XUNITS + YUNITS);
+  constexpr int UPW = (UNITS_PER_STEP + 3) / 4;                // units per wave per step
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ct = wave / (IT * KS), it = (wave / KS) % IT, ks = wave % KS;
+
+  int t = blockIdx.x;
+  const int rs = t % p.row_splits;
+  t /= p.row_splits;
+  const int strip = t % p.strips;
+  const int n = t / p.strips;
+  const int x0 = strip * 32;
+  const int y_begin = rs * p.rows_per_wg;
+  const int y_end = min(y_begin + p.rows_per_wg, p.H);
+
+  const float* xn = p.x + (long long)n * p.x_ns;
+  const float* dyn = p.dy + (long long)n * p.dy_ns;
+  const long long xplane = (long long)p.x_h * p.x_w * 8, yplane = (long long)p.H * p.W * 8;
+  char* xring = smem;
+  char* yring = smem + XRING;
+
+  // Stage the rows a step needs: X rows [yx, yx+R) into their ring slots, dY rows [yy, yy+R).
+  // Units (1 KiB wave-instructions) are dealt round-robin to the 4 waves.
+  auto stage = [&](int yx, int yy, bool with_dy) {
+#pragma unroll
+    for (int uu = 0; uu < UPW; ++uu) {
+      const int u = uu * 4 + wave;
+      if (u >= UNITS_PER_STEP) break;
+      const int r = u / (XUNITS + YUNITS), v = u % (XUNITS + YUNITS);
+      if (v >= XUNITS && !with_dy) continue;
+      if (v < XUNITS) {
+        const int y = yx + r;  // output-space row of this X row; may be -1 or >= H (zero row)
+        const int q = v * 64 + lane;
+        const int pix = q / (XCH / 4), c4 = q % (XCH / 4);
+        const int cb = p.cin_tile0 * 4 + (c4 >> 1);
+        const int gx = x0 - 1 + pix;
+        const bool ok = (q < XPIECES) && y >= 0 && y < p.H && gx >= 0 && gx < p.W && cb < p.cin_blocks;
+        const int sy = UPS ? (y >> 1) : y, sx = UPS ? (gx >> 1) : gx;
+        const float* src = ok ? xn + cb * xplane + ((long long)sy * p.x_w + sx) * 8 + (c4 & 1) * 4 : g_zero_line_w;
+        const int slot = (y + 1 + NXR) % NXR;
+        glds16w(src, xring + slot * XROWB + v * 1024);
+      } else {
+        const int vy = v - XUNITS;
+        const int y = yy + r;
+        const int q = vy * 64 + lane;
+        const int pix = q / (YCH / 4), c4 = q % (YCH / 4);
+        const int cb = p.cout_tile0 * 4 + (c4 >> 1);
+        const int gx = x0 + pix;
+        const bool ok = y < p.H && gx < p.W && cb < p.cout_blocks;
+        const float* src = ok ? dyn + cb * yplane + ((long long)y * p.W + gx) * 8 + (c4 & 1) * 4 : g_zero_line_w;
+        const int slot = y % NYR;
+        glds16w(src, yring + slot * YROWB + vy * 1024);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  float bsum = 0.f;
+
+  const int a_lane = (h * YCH + ct * 32 + j) * 4;  // byte offset of A operand: pixel h of the pair, this lane's cout
+  const int b_lane = (h * XCH + it * 32 + j) * 4;  // byte offset of B operand: pixel h (+dx), this lane's cin
+
+  // Invariant at the top of step y: X rows y-1 .. y+R and dY rows y .. y+R-1 are in LDS.
+  // During step y the rows of step y+R arrive: X rows y+R+1 .. y+2R, dY rows y+R .. y+2R-1.
+  // Live X rows y-1 .. y+2R are 2R+2 consecutive rows = distinct ring slots; dY rows y .. y+2R-1 likewise.
+  stage(y_begin - 1, y_begin, true);
+  for (int r0 = y_begin - 1 + R; r0 <= y_begin + R; r0 += R) stage(r0, 0, false);
+  __syncthreads();
+  for (int y = y_begin; y < y_end; y += R) {
+    stage(y + R + 1, y + R, true);
+    const int row = ROWSPLIT ? y + ks : y;
+    const int s0 = ROWSPLIT ? 0 : ks * SN;
+    if (row < y_end) {
+      const char* ya = yring + (row % NYR) * YROWB + a_lane + s0 * 2 * YCH * 4;
+      const char* xb[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) xb[dy] = xring + ((row + dy) % NXR) * XROWB + b_lane + s0 * 2 * XCH * 4;
+#pragma unroll
+      for (int s = 0; s < SN; ++s) {
+        const float a = *(const float*)(ya + s * 2 * YCH * 4);
+        bsum += a;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float b = *(const float*)(xb[dy] + (s * 2 + dx) * XCH * 4);
+            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dy * 3 + dx], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+
+  // write this wave's partial tile:  slab[split][pair][tap][g][lane][4]
+  const int pair = ct * IT + it;
+  const long long split = (long long)blockIdx.x * KS + ks;
+  float* dst = p.slab + ((split * P + pair) * 9) * 1024 + lane * 4;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[tap][g * 4 + e];
+      *(f32x4*)(dst + tap * 1024 + g * 256) = v;
+    }
+  if (p.bslab && it == 0) {
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0) p.bslab[(split * CT + ct) * 32 + j] = bsum;
+  }
+}
+
+// Sums the slab over splits and scatters to OIHW.  One thread per slab element of one split.
+// Element (pair, tap, g, lane, e):  cout = ct*32 + 8g + 4(lane>>5) + e,  cin position = it*32 + (lane&31).
+struct ReduceParams {
+  const float* slab;
+  const float* bslab;
+  float* dw;  // [cout][cin][3][3]
+  float* db;  // [cout] or null
+  int splits, P, IT, CT;
+  int cin_tile0, cout_tile0;
+  int cout, cin, first_seg, seg;  // reference channel counts and concat segmentation
+  float scale;
+  int accumulate;
+};
+
+__global__ void wgrad_reduce_kernel(const ReduceParams p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_split = p.P * 9 * 1024;
+  if (idx < per_split) {
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += p.slab[(long long)k * per_split + idx];
+    const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3;
+    const int tap = (idx >> 10) % 9, pair = idx / (9 * 1024);
+    const int ct = pair / p.IT, it = pair % p.IT;
+    const int co = (p.cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5) + e;
+    const int pos = (p.cin_tile0 + it) * 32 + (lane & 31);
+    // invert the concat position map of sr_conv3x3_pack_f32
+    int ci = -1;
+    const int fsp = (p.first_seg + 7) / 8 * 8;
+    if (pos < fsp) {
+      if (pos < p.first_seg) ci = pos;
+    } else if (p.seg > 0) {
+      const int sp = (p.seg + 7) / 8 * 8;
+      const int r = pos - fsp, sgi = r / sp, o = r % sp;
+      if (o < p.seg) ci = p.first_seg + sgi * p.seg + o;
+    }
+    if (co < p.cout && ci >= 0 && ci < p.cin) {
+      float* o = p.dw + ((long long)co * p.cin + ci) * 9 + tap;
+      *o = p.accumulate ? *o + s * p.scale : s * p.scale;
+    }
+  }
+  if (p.db && p.bslab && idx < p.CT * 32) {
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += p.bslab[(long long)k * p.CT * 32 + idx];
+    const int co = p.cout_tile0 * 32 + idx;
+    if (co < p.cout) p.db[co] = p.accumulate ? p.db[co] + s * p.scale : s * p.scale;
+  }
+}
+
+template <int CT, int IT, int R>
+constexpr int wgrad_lds_bytes() {
+  constexpr int XUNITS = (34 * (32 * IT / 4) + 63) / 64, YUNITS = 4 * CT;
+  return (2 * R + 2) * XUNITS * 1024 + 2 * R * YUNITS * 1024;
+}
+
+template <int CT, int IT, int R>
+int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, float* slab, float* bslab,
+                 bool want_bias, hipStream_t stream) {
+  constexpr int P = CT * IT, KS = 4 / P;
+  constexpr int lds = wgrad_lds_bytes<CT, IT, R>();
+  p.cin_tile0 = cin_tile0;
+  p.cout_tile0 = cout_tile0;
+  // rows per workgroup: aim at >= 512 workgroups (2 per CU), multiple of R, at least 4R rows to amortise the prologue
+  const long long strips_total = (long long)d->n * p.strips;
+  int rows = p.H;
+  while (rows > 4 * R && strips_total * sr::cdiv(p.H, rows) < 512) rows = (rows + 1) / 2;
+  rows = (rows + R - 1) / R * R;
+  p.rows_per_wg = rows;
+  p.row_splits = sr::cdiv(p.H, rows);
+  const long long nwg = strips_total * p.row_splits;
+  const long long splits = nwg * KS;
+  if ((size_t)splits * P * 9 * 1024 * sizeof(float) > d->slab_bytes ||
+      (size_t)splits * CT * 32 * sizeof(float) > d->slab_bytes / 63) {
+    sr::set_error("sr_conv3x3_wgrad_f32: slab %zu B too small (need %zu B)", d->slab_bytes,
+                  (size_t)splits * P * 9 * 1024 * sizeof(float));
+    return SR_ENOSPACE;
+  }
+  p.slab = slab;
+  p.bslab = want_bias ? bslab : nullptr;
+  auto kern = d->upsample ? wgrad3x3_f32_kernel<CT, IT, R, true> : wgrad3x3_f32_kernel<CT, IT, R, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[d->upsample ? 1 : 0]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      sr::set_error("wgrad: hipFuncSetAttribute(%d) failed", lds);
+      return SR_ELAUNCH;
+    }
+    attr_set[d->upsample ? 1 : 0] = true;
+  }
+  const bool prof = sr::prof_on();
+  if (prof) {
+    sr_launch_record r = {};
+    r.kernel_id = 8 + (CT == 2 ? (IT == 2 ? 3 : 4) : (IT == 4 ? 2 : (IT == 2 ? 1 : 0)));
+    r.cin = 32 * IT;
+    r.cout = 32 * CT;
+    r.n = d->n;
+    r.h = p.H;
+    r.w = p.W;
+    const double px = (double)d->n * p.H * p.W;
+    const int cin_eff = min(32 * IT, d->cin_pad - 32 * cin_tile0), cout_eff = min(32 * CT, d->cout - 32 * cout_tile0);
+    r.flops = 2.0 * 9.0 * cin_eff * cout_eff * px;
+    r.bytes = 4.0 * px * (cin_eff + cout_eff);
+    sr::prof_begin(stream, r);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+  if (prof) sr::prof_end(stream);
+  SR_CHECK_LAUNCH("wgrad3x3_f32 launch");
+  ReduceParams rp;
+  rp.slab = slab;
+  rp.bslab = want_bias ? bslab : nullptr;
+  rp.dw = d->dweight;
+  rp.db = want_bias ? d->dbias : nullptr;
+  rp.splits = (int)splits;
+  rp.P = P;
+  rp.IT = IT;
+  rp.CT = CT;
+  rp.cin_tile0 = cin_tile0;
+  rp.cout_tile0 = cout_tile0;
+  rp.cout = d->cout;
+  rp.cin = d->cin;
+  rp.first_seg = d->first_seg;
+  rp.seg = d->seg;
+  rp.scale = d->scale;
+  rp.accumulate = d->accumulate;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((P * 9 * 1024 + 255) / 256), dim3(256), 0, stream, rp);
+  SR_CHECK_LAUNCH("wgrad_reduce launch");
+  return SR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sr_conv3x3_wgrad_slab_bytes(int n, int h, int w) {
+  // splits*P = 4 * workgroups for every launch shape; the row-range heuristic of launch_group stops
+  // halving once it has >= 512 workgroups, so workgroups < max(strips, 1024).  1/64 of the slab is bias partials.
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  const long long strips = (long long)n * ((w + 31) / 32);
+  const long long nwg = strips > 1024 ? strips : 1024;
+  const size_t wbytes = (size_t)nwg * 4 * 9 * 1024 * sizeof(float);
+  return (wbytes + wbytes / 32 + 4096) / 256 * 256;
+}
+
+extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(d && d->x && d->dy && d->dweight && d->slab, "sr_conv3x3_wgrad_f32: null argument");
+  SR_CHECK_ARG(d->cout > 0 && d->cin > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_wgrad_f32: bad shape");
+  const int cin_pad = sr_conv3x3_cin_pad(d->cin, d->first_seg, d->seg);
+  SR_CHECK_ARG(cin_pad > 0 && cin_pad == d->cin_pad, "sr_conv3x3_wgrad_f32: cin_pad=%d does not match cin=%d/%d/%d",
+               d->cin_pad, d->cin, d->first_seg, d->seg);
+  SR_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->slab) % 16 == 0,
+               "sr_conv3x3_wgrad_f32: pointers must be 16-byte aligned");
+  WgradParams p = {};
+  p.x = d->x;
+  p.dy = d->dy;
+  p.x_ns = d->x_img_stride;
+  p.dy_ns = d->dy_img_stride;
+  p.x_h = d->in_h;
+  p.x_w = d->in_w;
+  p.H = d->upsample ? 2 * d->in_h : d->in_h;
+  p.W = d->upsample ? 2 * d->in_w : d->in_w;
+  p.cin_blocks = cin_pad / 8;
+  p.cout_blocks = (d->cout + 7) / 8;
+  p.strips = sr::cdiv(p.W, 32);
+  const int cts = sr::cdiv(d->cout, 32), its = sr::cdiv(cin_pad, 32);
+  // bias slab sits behind the weight slab region
+  const size_t wslab_bytes = (d->slab_bytes - d->slab_bytes / 64) / 256 * 256;
+  float* slab = (float*)d->slab;
+  float* bslab = (float*)((char*)d->slab + wslab_bytes);
+  sr_conv3x3_wgrad_desc dd = *d;
+  dd.slab_bytes = wslab_bytes;
+  // Walk the (cout tile, cin tile) grid in workgroup-sized groups: 2x2, 1x4, 1x2, 2x1, 1x1.
+  for (int c0 = 0; c0 < cts;) {
+    const int cn = (cts - c0 >= 2) ? 2 : 1;
+    for (int i0 = 0; i0 < its;) {
+      const int left = its - i0;
+      const bool bias = d->dbias != nullptr && i0 == 0;
+      int rc, in;
+      if (cn == 2) {
+        if (left >= 2) {
+          in = 2;
+          rc = launch_group<2, 2, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+        } else {
+          in = 1;
+          rc = launch_group<2, 1, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+        }
+      } else {
+        if (left >= 4) {
+          in = 4;
+          rc = launch_group<1, 4, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+        } else if (left >= 2) {
+          in = 2;
+          rc = launch_group<1, 2, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+        } else {
+          in = 1;
+          rc = launch_group<1, 1, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+        }
+      }
+      if (rc) return rc;
+      i0 += in;
+    }
+    c0 += cn;
+  }
+  return SR_OK;
+}

@@ -72,7 +72,7 @@ def cb8_to_nchw(t, channels):
     lib = _lib.load()
     y = torch.empty((t.n, channels, t.h, t.w), dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
-        _lib.check(lib.sr_cb8_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w,
+        _lib.check(lib.sr_cb8_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w, 1,
                                           _stream(t.device)), 'sr_cb8_to_nchw_f32')
     return y
 
@@ -145,3 +145,51 @@ def conv3x3(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1
     with torch.cuda.device(src.device):
         _lib.check(lib.sr_conv3x3_f32(C.byref(d), _stream(src.device)), 'sr_conv3x3_f32')
     return ret
+
+
+def conv3x3_wgrad(src, dy, cout, cin, first_seg=None, seg=0, *, upsample=False, scale=1.0, want_bias=True):
+    """(dweight [cout,cin,3,3], dbias [cout]) of a 3x3 conv whose source was ``src`` (CB8) and whose
+    pre-activation output gradient is ``dy`` (CB8) — one sr_conv3x3_wgrad_f32 call."""
+    lib = _lib.load()
+    first_seg = cin if first_seg is None else first_seg
+    cin_pad = lib.sr_conv3x3_cin_pad(cin, first_seg, seg)
+    assert src.channels == cin_pad, (src.channels, cin_pad)
+    H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
+    assert (dy.n, dy.h, dy.w) == (src.n, H, W) and dy.channels >= (cout + 7) // 8 * 8
+    dev = src.device
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = lib.sr_conv3x3_wgrad_slab_bytes(src.n, H, W)
+    slab = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d = _lib.WgradDesc()
+    d.x, d.x_img_stride, d.cin_pad, d.in_h, d.in_w, d.upsample = src.ptr, src.img_stride, cin_pad, src.h, src.w, int(upsample)
+    d.dy, d.dy_img_stride = dy.ptr, dy.img_stride
+    d.cout, d.cin, d.first_seg, d.seg, d.n, d.scale = cout, cin, first_seg, seg, src.n, scale
+    d.dweight, d.dbias, d.accumulate = dw.data_ptr(), (db.data_ptr() if db is not None else None), 0
+    d.slab, d.slab_bytes = slab.data_ptr(), nbytes
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_conv3x3_wgrad_f32(C.byref(d), _stream(dev)), 'sr_conv3x3_wgrad_f32')
+    return dw, db
+
+
+def upsample2x_bwd(g, mask=None, mask_slope=0.2):
+    """2x2-sum backward of the nearest upsample (+ optional LeakyReLU backward) — sr_upsample2x_bwd_f32."""
+    lib = _lib.load()
+    assert g.h % 2 == 0 and g.w % 2 == 0
+    out = CB8.empty(g.n, g.channels, g.h // 2, g.w // 2, g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.sr_upsample2x_bwd_f32(g.ptr, g.img_stride, out.ptr, out.img_stride,
+                                             mask.ptr if mask is not None else None,
+                                             mask.img_stride if mask is not None else 0, mask_slope, g.n, g.cbn,
+                                             out.h, out.w, _stream(g.device)), 'sr_upsample2x_bwd_f32')
+    return out
+
+
+def cb8_axpby(dst, src, a=1.0, b=1.0):
+    """dst = a*dst + b*src on CB8 windows — sr_cb8_axpby_f32."""
+    lib = _lib.load()
+    assert (dst.n, dst.cbn, dst.h, dst.w) == (src.n, src.cbn, src.h, src.w)
+    with torch.cuda.device(dst.device):
+        _lib.check(lib.sr_cb8_axpby_f32(dst.ptr, dst.img_stride, src.ptr, src.img_stride, a, b, dst.n, dst.cbn, dst.h,
+                                        dst.w, _stream(dst.device)), 'sr_cb8_axpby_f32')
+    return dst

@@ -55,9 +55,19 @@ const char* sr_last_error(void);
  * dst has `dst_cblocks` channel blocks (>= ceil(C*u*u/8)); pad channels are zeroed. */
 int sr_nchw_to_cb8_f32(const float* src, float* dst, int N, int C, int H, int W, int unshuffle,
                        int dst_cblocks, int64_t dst_img_stride, void* stream);
-/* CB8 -> NCHW fp32, first C channels. */
-int sr_cb8_to_nchw_f32(const float* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W,
+/* CB8 -> NCHW fp32, first C*shuffle^2 channels; `shuffle` in {1,2,4} is the inverse of `unshuffle`
+ * above (dst is [N][C][H*shuffle][W*shuffle]); used for the input gradient at scale 2 / 1. */
+int sr_cb8_to_nchw_f32(const float* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W, int shuffle,
                        void* stream);
+
+/* Backward of the head's nearest-x2 upsample (autograd of F.interpolate, rrdbnet_arch.py:116-117):
+ * dst[n][cb][y][x] = sum of the 2x2 block of g; optional LeakyReLU backward against `mask`
+ * (the activation tensor that was upsampled; NULL = none). g is [.., 2h, 2w], dst/mask [.., h, w]. */
+int sr_upsample2x_bwd_f32(const float* g, int64_t g_img_stride, float* dst, int64_t dst_img_stride, const float* mask,
+                          int64_t mask_img_stride, float mask_slope, int n, int cblocks, int h, int w, void* stream);
+/* dst = a*dst + b*src on CB8 windows of `cblocks` channel blocks (residual-branch gradient sums). */
+int sr_cb8_axpby_f32(float* dst, int64_t dst_img_stride, const float* src, int64_t src_img_stride, float a, float b,
+                     int n, int cblocks, int h, int w, void* stream);
 
 /* ------------------------------------------------------------- conv3x3 ------ */
 
@@ -100,6 +110,7 @@ typedef struct sr_conv3x3_desc {
   float alpha;            /* out = alpha*act(conv+bias) + beta1*res1 + beta2*res2 */
   const float* res1; int64_t res1_img_stride; float beta1;  /* CB8, same shape as out; NULL = none */
   const float* res2; int64_t res2_img_stride; float beta2;
+  int res_cbn;            /* residuals apply to the first res_cbn channel blocks of out only (0 = all) */
   int accumulate;         /* 1: out += result (dgrad accumulation into a concat-gradient buffer) */
   const float* mask_src;  /* optional CB8 tensor of mask_cbn channel blocks: where mask_src <= 0 the
                              final value is multiplied by mask_slope — LeakyReLU backward fused on
@@ -113,6 +124,30 @@ typedef struct sr_conv3x3_desc {
  * ResidualDenseBlock.forward (rrdbnet_arch.py:32-39), RRDB.forward (:58-63) and the
  * trunk/head convs of RRDBNet.forward (:112-118). */
 int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream);
+
+/* Weight / bias gradient of the same convolution (what autograd computes for nn.Conv2d in
+ * ESRGANModel.optimize_parameters' backward calls, esrgan_model.py:47,68,72):
+ *   dweight[co][ci][tap] (+)= scale * sum_{n,y,x} dy[co][y][x] * x[ci][y+dy-1][x+dx-1],  dbias[co] (+)= scale * sum dy[co]
+ * Deterministic: partial sums go through a caller-provided slab, no atomics. */
+typedef struct sr_conv3x3_wgrad_desc {
+  const float* x;          /* CB8 forward source of the conv (channel slice allowed) */
+  int64_t x_img_stride;
+  int cin_pad;             /* = sr_conv3x3_cin_pad(cin, first_seg, seg) */
+  int in_h, in_w;          /* source spatial size */
+  int upsample;            /* 1: the conv read x through the nearest-x2 upsample */
+  const float* dy;         /* CB8 gradient wrt the conv's pre-activation output, roundup8(cout) channels */
+  int64_t dy_img_stride;
+  int cout, cin, first_seg, seg; /* reference channel counts + concat segmentation (see sr_conv3x3_pack_f32) */
+  int n;
+  float scale;
+  float* dweight;          /* OIHW [cout][cin][3][3] */
+  float* dbias;            /* [cout] or NULL */
+  int accumulate;          /* 1: add into dweight/dbias instead of overwriting */
+  void* slab;              /* >= sr_conv3x3_wgrad_slab_bytes(n, out_h, out_w) */
+  size_t slab_bytes;
+} sr_conv3x3_wgrad_desc;
+size_t sr_conv3x3_wgrad_slab_bytes(int n, int out_h, int out_w);
+int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream);
 
 /* ------------------------------------------------------- whole generator ---- */
 
@@ -134,6 +169,24 @@ int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_para
  * y NCHW [n][num_out_ch][4h/s'][4w/s'] where s' = 1, 2, 4 for scale 4, 2, 1. */
 int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h,
                            int w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Training: forward that KEEPS every activation the backward needs (one concat buffer per dense block,
+ * 3*num_block+1 of them, plus the head maps) in `saved`, and the matching backward.
+ *   sr_rrdbnet_forward_train_f32  == RRDBNet.forward under autograd (esrgan_model.py:18)
+ *   sr_rrdbnet_backward_f32       == autograd's backward through it (esrgan_model.py:47): given dL/dy it writes
+ *       dL/dparam for every parameter (host_dparams: HOST array of DEVICE pointers in state_dict order, each
+ *       shaped like its parameter; NULL entries are skipped) and, if dx != NULL, dL/dx.
+ * packed_dgrad holds the transposed/flipped weight images (sr_rrdbnet_pack_dgrad_f32). */
+size_t sr_rrdbnet_saved_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+size_t sr_rrdbnet_backward_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+size_t sr_rrdbnet_packed_dgrad_bytes(const sr_rrdbnet_cfg* cfg);
+int sr_rrdbnet_pack_dgrad_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_params, float* packed_dgrad,
+                              void* stream);
+int sr_rrdbnet_forward_train_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h,
+                                 int w, void* saved, size_t saved_bytes, void* stream);
+int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad, const void* saved, size_t saved_bytes,
+                            const float* dy, int n, int h, int w, float* const* host_dparams, float* dx,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------ measurement ---- */
 
