@@ -19,7 +19,9 @@ void set_error(const char* fmt, ...) {
 extern "C" int sr_version(void) { return SR_ABI_VERSION; }
 extern "C" const char* sr_last_error(void) { return g_err; }
 
-// ---- opt-in launch profiler (thread-local; off unless sr_profile_start was called) ----
+// ---- opt-in launch profiler (process-wide, mutex-guarded; off unless sr_profile_start was called).
+// Process-wide because autograd runs the backward launches on its own thread. ----
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -29,12 +31,18 @@ struct ProfState {
   std::vector<sr_launch_record> recs;
   std::vector<hipEvent_t> ev;  // 2 per record
 };
-thread_local ProfState g_prof;
+ProfState g_prof;
+std::mutex g_prof_mu;
 }  // namespace
 
 namespace sr {
-bool prof_on() { return g_prof.on && g_prof.recs.size() < g_prof.cap; }
+bool prof_on() {
+  if (!g_prof.on) return false;  // unsynchronised fast path: the flag only flips inside start/stop
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  return g_prof.on && g_prof.recs.size() < g_prof.cap;
+}
 void prof_begin(hipStream_t s, const sr_launch_record& r) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
@@ -43,11 +51,15 @@ void prof_begin(hipStream_t s, const sr_launch_record& r) {
   g_prof.ev.push_back(a);
   g_prof.ev.push_back(b);
 }
-void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.ev.back(), s); }
+void prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_prof.ev.back(), s);
+}
 }  // namespace sr
 
 extern "C" int sr_profile_start(int max_records) {
   SR_CHECK_ARG(max_records > 0, "sr_profile_start: max_records must be positive");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   SR_CHECK_ARG(!g_prof.on, "sr_profile_start: already recording");
   g_prof.on = true;
   g_prof.cap = (size_t)max_records;
@@ -57,6 +69,7 @@ extern "C" int sr_profile_start(int max_records) {
 }
 
 extern "C" int sr_profile_stop(sr_launch_record* out, int capacity, int* count) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   SR_CHECK_ARG(g_prof.on, "sr_profile_stop: not recording");
   g_prof.on = false;
   int rc = SR_OK;

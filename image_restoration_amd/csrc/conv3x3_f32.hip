@@ -338,5 +338,9 @@ extern "C" const char* sr_kernel_name(int id) {
       "conv3x3_f32_kernelILi1ELi2ELb0ELb0E", "conv3x3_f32_kernelILi1ELi2ELb0ELb1E", "conv3x3_f32_kernelILi1ELi2ELb1ELb0E",
       "conv3x3_f32_kernelILi1ELi2ELb1ELb1E", "conv3x3_f32_kernelILi2ELi2ELb0ELb0E", "conv3x3_f32_kernelILi2ELi2ELb0ELb1E",
       "conv3x3_f32_kernelILi2ELi2ELb1ELb0E", "conv3x3_f32_kernelILi2ELi2ELb1ELb1E"};
+  static const char* wnames[5] = {"wgrad3x3_f32_kernelILi1ELi1ELi1E", "wgrad3x3_f32_kernelILi1ELi2ELi1E",
+                                  "wgrad3x3_f32_kernelILi1ELi4ELi1E", "wgrad3x3_f32_kernelILi2ELi2ELi1E",
+                                  "wgrad3x3_f32_kernelILi2ELi1ELi1E"};
+  if (id >= 8 && id < 13) return wnames[id - 8];
   return (id >= 0 && id < 8) ? names[id] : "";
 }

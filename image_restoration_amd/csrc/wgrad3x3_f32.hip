@@ -181,26 +181,79 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
   }
 }
 
-// Sums the slab over splits and scatters to OIHW.  One thread per slab element of one split.
-// Element (pair, tap, g, lane, e):  cout = ct*32 + 8g + 4(lane>>5) + e,  cin position = it*32 + (lane&31).
+// Slab reduction, two deterministic stages.
+// Stage 1: grid (E4/256, SCH): block (x, sc) sums the splits of chunk sc for 256 float4 columns
+//          (coalesced 4 KiB rows, 8 independent loads in flight per lane) into part[sc][E].
+// Stage 2: one thread per element sums the SCH partials in fixed order, applies the scale and scatters to
+//          OIHW.  Element (pair, tap, g, lane, e): cout = ct*32 + 8g + 4(lane>>5) + e, cin position = it*32 + (lane&31).
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
+                                                            int e4, int splits, int chunk,
+                                                            const float* __restrict__ bslab, float* __restrict__ bpart,
+                                                            int nb) {
+  const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, splits);
+  if (blockIdx.x == gridDim.x - 1) {  // the extra block column reduces the bias partials of this chunk
+    if (bslab && (int)threadIdx.x < nb) {
+      float b = 0.f;
+      int s = s0;
+      for (; s + 8 <= s1; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = bslab[(long long)(s + u) * nb + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b += v[u];
+      }
+      for (; s < s1; ++s) b += bslab[(long long)s * nb + threadIdx.x];
+      bpart[blockIdx.y * nb + threadIdx.x] = b;
+    }
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= e4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p = slab + (long long)s0 * e4 + i;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)u * e4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += v[u].x;
+      acc.y += v[u].y;
+      acc.z += v[u].z;
+      acc.w += v[u].w;
+    }
+    p += (long long)8 * e4;
+  }
+  for (; s < s1; ++s) {
+    const float4 v = *p;
+    acc.x += v.x;
+    acc.y += v.y;
+    acc.z += v.z;
+    acc.w += v.w;
+    p += e4;
+  }
+  part[(long long)blockIdx.y * e4 + i] = acc;
+}
+
 struct ReduceParams {
-  const float* slab;
-  const float* bslab;
-  float* dw;  // [cout][cin][3][3]
-  float* db;  // [cout] or null
-  int splits, P, IT, CT;
+  const float* part;   // [sch][P*9*1024]
+  const float* bpart;  // [sch][CT*32]
+  float* dw;           // [cout][cin][3][3]
+  float* db;           // [cout] or null
+  int sch, splits, P, IT, CT;
   int cin_tile0, cout_tile0;
   int cout, cin, first_seg, seg;  // reference channel counts and concat segmentation
   float scale;
   int accumulate;
 };
 
-__global__ void wgrad_reduce_kernel(const ReduceParams p) {
+__global__ void wgrad_reduce2_kernel(const ReduceParams p) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_split = p.P * 9 * 1024;
   if (idx < per_split) {
     float s = 0.f;
-    for (int k = 0; k < p.splits; ++k) s += p.slab[(long long)k * per_split + idx];
+    for (int k = 0; k < p.sch; ++k) s += p.part[(long long)k * per_split + idx];
     const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3;
     const int tap = (idx >> 10) % 9, pair = idx / (9 * 1024);
     const int ct = pair / p.IT, it = pair % p.IT;
@@ -221,9 +274,9 @@ __global__ void wgrad_reduce_kernel(const ReduceParams p) {
       *o = p.accumulate ? *o + s * p.scale : s * p.scale;
     }
   }
-  if (p.db && p.bslab && idx < p.CT * 32) {
+  if (p.db && p.bpart && idx < p.CT * 32) {
     float s = 0.f;
-    for (int k = 0; k < p.splits; ++k) s += p.bslab[(long long)k * p.CT * 32 + idx];
+    for (int k = 0; k < p.sch; ++k) s += p.bpart[k * p.CT * 32 + idx];
     const int co = p.cout_tile0 * 32 + idx;
     if (co < p.cout) p.db[co] = p.accumulate ? p.db[co] + s * p.scale : s * p.scale;
   }
@@ -286,11 +339,23 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("wgrad3x3_f32 launch");
+  // stage 1 partials live behind the bias slab
+  const int e4 = P * 9 * 256;
+  int sch = (int)((splits + 63) / 64);
+  if (sch > 64) sch = 64;
+  const int chunk = (int)((splits + sch - 1) / sch);
+  sch = (int)((splits + chunk - 1) / chunk);
+  float* part = (float*)((char*)bslab + d->slab_bytes / 63 / 256 * 256);
+  float* bpart = part + (size_t)64 * 4 * 9 * 1024;  // behind the weight partials
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch), dim3(256), 0, stream, (const float4*)slab,
+                     (float4*)part, e4, (int)splits, chunk, want_bias ? bslab : nullptr, bpart, CT * 32);
+  SR_CHECK_LAUNCH("wgrad_reduce1 launch");
   ReduceParams rp;
-  rp.slab = slab;
-  rp.bslab = want_bias ? bslab : nullptr;
+  rp.part = part;
+  rp.bpart = want_bias ? bpart : nullptr;
   rp.dw = d->dweight;
   rp.db = want_bias ? d->dbias : nullptr;
+  rp.sch = sch;
   rp.splits = (int)splits;
   rp.P = P;
   rp.IT = IT;
@@ -303,8 +368,8 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   rp.seg = d->seg;
   rp.scale = d->scale;
   rp.accumulate = d->accumulate;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((P * 9 * 1024 + 255) / 256), dim3(256), 0, stream, rp);
-  SR_CHECK_LAUNCH("wgrad_reduce launch");
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((P * 9 * 1024 + 255) / 256), dim3(256), 0, stream, rp);
+  SR_CHECK_LAUNCH("wgrad_reduce2 launch");
   return SR_OK;
 }
 
@@ -317,7 +382,8 @@ extern "C" size_t sr_conv3x3_wgrad_slab_bytes(int n, int h, int w) {
   const long long strips = (long long)n * ((w + 31) / 32);
   const long long nwg = strips > 1024 ? strips : 1024;
   const size_t wbytes = (size_t)nwg * 4 * 9 * 1024 * sizeof(float);
-  return (wbytes + wbytes / 32 + 4096) / 256 * 256;
+  const size_t part_bytes = (size_t)64 * 4 * 9 * 1024 * sizeof(float) + 64 * 64 * sizeof(float) + 4096;
+  return (wbytes + wbytes / 32 + 2 * part_bytes + 4096) / 256 * 256;
 }
 
 extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
@@ -343,7 +409,9 @@ extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream
   p.strips = sr::cdiv(p.W, 32);
   const int cts = sr::cdiv(d->cout, 32), its = sr::cdiv(cin_pad, 32);
   // bias slab sits behind the weight slab region
-  const size_t wslab_bytes = (d->slab_bytes - d->slab_bytes / 64) / 256 * 256;
+  const size_t part_bytes = (size_t)64 * 4 * 9 * 1024 * sizeof(float) + 64 * 64 * sizeof(float) + 4096;
+  SR_CHECK_ARG(d->slab_bytes > 2 * part_bytes, "sr_conv3x3_wgrad_f32: slab too small");
+  const size_t wslab_bytes = (d->slab_bytes - part_bytes) / 64 * 63 / 256 * 256;
   float* slab = (float*)d->slab;
   float* bslab = (float*)((char*)d->slab + wslab_bytes);
   sr_conv3x3_wgrad_desc dd = *d;

@@ -191,8 +191,9 @@ int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad
 /* ------------------------------------------------------------ measurement ---- */
 
 /* Opt-in per-launch timing used by bench.py's roofline line: between sr_profile_start and
- * sr_profile_stop every conv launch issued by the calling thread is bracketed by HIP events
- * recorded on the launch's own stream.  sr_profile_stop synchronises on those events only. */
+ * sr_profile_stop every conv / wgrad launch issued by the process (any thread: autograd runs
+ * backward on its own) is bracketed by HIP events recorded on the launch's own stream.
+ * sr_profile_stop synchronises on those events only.  One recording session at a time. */
 typedef struct sr_launch_record {
   int32_t kernel_id;          /* index for sr_kernel_name */
   int32_t cin, cout, n, h, w; /* real channels, batch, OUTPUT spatial size */
