@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
         ('act_slope', C.c_float), ('alpha', C.c_float),
         ('res1', C.c_void_p), ('res1_img_stride', C.c_int64), ('beta1', C.c_float),
         ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float), ('res_cbn', C.c_int),
-        ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
+        ('out_h', C.c_int), ('out_w', C.c_int), ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
         ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float),
     ]
 
@@ -65,8 +65,13 @@ SIGNATURES = {
     'sr_conv3x3_pack_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_conv3x3_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'sr_conv4x4s2_packed_weight_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'sr_conv4x4s2_pack_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_conv4x4s2_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'sr_conv4x4s2_dgrad_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'sr_conv3x3_wgrad_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_wgrad_f32': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    'sr_conv4x4s2_wgrad_f32': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'sr_rrdbnet_num_params': (C.c_int, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_packed_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),

@@ -1,4 +1,5 @@
-// Fused 3x3 convolution on fp32 MFMA for gfx950 (MI355X).
+// Fused convolution on fp32 MFMA for gfx950 (MI355X): 3x3/s1 (generator, discriminators) and, as four
+// parity passes of a 2x2 tap grid, 4x4/s2 (discriminators) and its data gradient.
 //
 // Replaces, on the RRDBNet path, nn.Conv2d(k3,s1,p1) + LeakyReLU(0.2) + torch.cat +
 // the 0.2 residual scale-adds of the reference
@@ -40,9 +41,16 @@ struct ConvParams {
   int cin_blocks;   // Cin / 8
   int cout_blocks;  // valid 8-channel blocks of the destination
   int cout;         // real cout (NCHW store)
-  int in_h, in_w;   // source spatial size
-  int H, W;         // output spatial size
+  int in_h, in_w;   // real source spatial size
+  int H, W;         // compute-space output size (tiles cover this)
   int tiles_x, tiles_y;
+  // Source map: tap (ty,tx) of compute pixel (y,x) reads VIRTUAL pixel (y+tap_oy+ty, x+tap_ox+tx), valid inside
+  // [0,vH)x[0,vW), which is REAL pixel ((v*src_mul)>>src_shift)+src_o.  3x3/s1: identity, tap_o = -1; nearest x2
+  // upsample: shift 1; parity sub-image of a stride-2 conv: mul 2, off = parity.
+  int vH, vW, src_mul, src_shift, src_oy, src_ox, tap_oy, tap_ox;
+  // Destination map: compute pixel (y,x) is REAL pixel (y*dst_mul+dst_oy, x*dst_mul+dst_ox) of an oH x oW image.
+  int oH, oW, dst_mul, dst_oy, dst_ox;
+  int acc_first;    // accumulate the old destination value BEFORE bias/activation (last pass of a multi-pass conv)
   int mask_cb0, mask_cb1;
   int res_cb1;      // residuals apply to destination blocks [0, res_cb1)
   float slope, alpha, beta1, beta2, mask_slope;
@@ -54,12 +62,12 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int COT, int PT, bool UPS, bool NCHW_OUT>
-__global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
+template <int COT, int PT, int KS, bool NCHW_OUT>
+__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TH = 4 * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+  constexpr int TH = 4 * PT, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
-  constexpr int NXU = XBYTES / 1024, NWU = 9 * COT;
+  constexpr int NXU = XBYTES / 1024, NWU = KS * KS * COT;
   constexpr int WBYTES = NWU * 1024, STAGE = XBYTES + WBYTES;
   constexpr int NXR = (NXU + 3) / 4, NWR = (NWU + 3) / 4;
 
@@ -94,9 +102,9 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
     const int q = u * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
-    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
+    const int gy = y0 + p.tap_oy + row, gx = x0 + p.tap_ox + col;
+    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.vH && gx >= 0 && gx < p.vW;
+    const int sy = ((gy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
     xoff[r] = valid ? ((sy * p.in_w + sx) * 8 + half * 4) : -1;
   }
 
@@ -135,10 +143,10 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
     const char* xs = smem + buf * STAGE + xlane;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
+    for (int dy = 0; dy < KS; ++dy) {
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int tap = dy * 3 + dx;
+      for (int dx = 0; dx < KS; ++dx) {
+        const int tap = dy * KS + dx;
         f32x4 a[COT], b[PT];
 #pragma unroll
         for (int c = 0; c < COT; ++c) a[c] = *(const f32x4*)(ws + (tap * COT + c) * 1024);
@@ -164,14 +172,16 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
     __syncthreads();  // drains the LDS-DMA of chunk c+1 and frees buffer c&1
   }
 
-  // ---- epilogue: bias, LeakyReLU, residual scale-adds, optional accumulate / LReLU-backward mask
+  // ---- epilogue: [old +] bias, LeakyReLU, residual scale-adds, optional accumulate / LReLU-backward mask
   const int x = x0 + j;
-  const long long HW = (long long)p.H * p.W;
+  const long long HW = (long long)p.oH * p.oW;
+  const int rx = x * p.dst_mul + p.dst_ox;
 #pragma unroll
   for (int r = 0; r < PT; ++r) {
     const int y = y0 + wave * PT + r;
-    if (y >= p.H || x >= p.W) continue;
-    const long long pixoff = (long long)y * p.W + x;
+    const int ry = y * p.dst_mul + p.dst_oy;
+    if (y >= p.H || x >= p.W || ry >= p.oH || rx >= p.oW) continue;
+    const long long pixoff = (long long)ry * p.oW + rx;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
 #pragma unroll
@@ -181,6 +191,11 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[c][r][g * 4 + e];
+        const long long off = (cb * HW + pixoff) * 8 + h * 4;
+        float* o = p.out + (long long)n * p.out_ns + off;
+        if constexpr (!NCHW_OUT) {
+          if (p.accumulate && p.acc_first) v += *(const f32x4*)o;
+        }
         if (p.bias) {
           const f32x4 bv = *(const f32x4*)(p.bias + cb * 8 + h * 4);
           v += bv;
@@ -188,19 +203,17 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         v *= p.alpha;
-        const long long off = (cb * HW + pixoff) * 8 + h * 4;
         if (p.res1 && cb < p.res_cb1) v += p.beta1 * *(const f32x4*)(p.res1 + (long long)n * p.res1_ns + off);
         if (p.res2 && cb < p.res_cb1) v += p.beta2 * *(const f32x4*)(p.res2 + (long long)n * p.res2_ns + off);
         if constexpr (NCHW_OUT) {
           if (h == 0 && cb == 0) {
-            float* o = p.out + (long long)n * p.out_ns + pixoff;
+            float* on = p.out + (long long)n * p.out_ns + pixoff;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (e < p.cout) o[e * HW] = v[e];
+              if (e < p.cout) on[e * HW] = v[e];
           }
         } else {
-          float* o = p.out + (long long)n * p.out_ns + off;
-          if (p.accumulate) v += *(const f32x4*)o;
+          if (p.accumulate && !p.acc_first) v += *(const f32x4*)o;
           if (p.mask && cb >= p.mask_cb0 && cb < p.mask_cb1) {
             const f32x4 m = *(const f32x4*)(p.mask + (long long)n * p.mask_ns + ((cb - p.mask_cb0) * HW + pixoff) * 8 + h * 4);
 #pragma unroll
@@ -213,16 +226,16 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const ConvParams p) {
   }
 }
 
-template <int COT, int PT>
+template <int COT, int PT, int KS>
 constexpr int conv_lds_bytes() {
-  return 2 * ((((4 * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
+  return 2 * ((((4 * PT + KS - 1) * (32 + KS - 1) * 32 + 1023) / 1024) * 1024 + KS * KS * COT * 1024);
 }
 
-template <int COT, int PT, bool UPS, bool NCHW_OUT>
+template <int COT, int PT, int KS, bool NCHW_OUT>
 int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
-  constexpr int lds = conv_lds_bytes<COT, PT>();
+  constexpr int lds = conv_lds_bytes<COT, PT, KS>();
   static bool attr_set = false;
-  auto kern = conv3x3_f32_kernel<COT, PT, UPS, NCHW_OUT>;
+  auto kern = conv_f32_kernel<COT, PT, KS, NCHW_OUT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -235,15 +248,15 @@ int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = (COT - 1) * 4 + (UPS ? 2 : 0) + (NCHW_OUT ? 1 : 0);
+    r.kernel_id = (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
     r.h = p.H;
     r.w = p.W;
     const double px = (double)n * p.H * p.W;
-    r.flops = 2.0 * 9.0 * r.cin * r.cout * px;
-    const double in_px = (double)n * p.in_h * p.in_w;
+    r.flops = 2.0 * KS * KS * r.cin * r.cout * px;
+    const double in_px = KS == 3 ? (double)n * p.in_h * p.in_w : px;  // a parity pass reads 1/4 of its source
     double fl = in_px * r.cin + px * r.cout;  // source once, destination once
     if (d->res1) fl += px * r.cout;
     if (d->res2) fl += px * r.cout;
@@ -254,7 +267,7 @@ int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
   if (prof) sr::prof_end(stream);
-  SR_CHECK_LAUNCH("conv3x3_f32 launch");
+  SR_CHECK_LAUNCH("conv_f32 launch");
   return SR_OK;
 }
 
@@ -268,19 +281,21 @@ int conv_group_couts(int cout) {
 }
 }  // namespace sr
 
-extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(d != nullptr, "sr_conv3x3_f32: null descriptor");
-  SR_CHECK_ARG(d->in && d->wpacked && d->out, "sr_conv3x3_f32: null in/wpacked/out");
-  SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 8 == 0, "sr_conv3x3_f32: cin_pad=%d must be a positive multiple of 8",
-               d->cin_pad);
-  SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_f32: bad shape");
-  SR_CHECK_ARG(!d->out_nchw || d->cout <= 4, "sr_conv3x3_f32: out_nchw needs cout <= 4 (got %d)", d->cout);
-  SR_CHECK_ARG(!(d->out_nchw && (d->accumulate || d->mask_src)), "sr_conv3x3_f32: out_nchw excludes accumulate/mask");
-  SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 |
-                (uintptr_t)d->res2 | (uintptr_t)d->mask_src | (uintptr_t)d->bpacked) % 16 == 0,
-               "sr_conv3x3_f32: pointers must be 16-byte aligned");
-  ConvParams p;
+namespace {
+
+// Fills the fields every entry point shares and validates the descriptor.
+int fill_common(const sr_conv3x3_desc* d, ConvParams* pp, const char* who) {
+  SR_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  SR_CHECK_ARG(d->in && d->wpacked && d->out, "%s: null in/wpacked/out", who);
+  SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 8 == 0, "%s: cin_pad=%d must be a positive multiple of 8", who, d->cin_pad);
+  SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "%s: bad shape", who);
+  SR_CHECK_ARG(!d->out_nchw || d->cout <= 4, "%s: out_nchw needs cout <= 4 (got %d)", who, d->cout);
+  SR_CHECK_ARG(!(d->out_nchw && (d->accumulate || d->mask_src)), "%s: out_nchw excludes accumulate/mask", who);
+  SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 | (uintptr_t)d->res2 |
+                (uintptr_t)d->mask_src | (uintptr_t)d->bpacked) % 16 == 0,
+               "%s: pointers must be 16-byte aligned", who);
+  ConvParams& p = *pp;
+  p = ConvParams{};
   p.in = d->in;
   p.w = d->wpacked;
   p.bias = d->bpacked;
@@ -298,8 +313,6 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   p.cout = d->cout;
   p.in_h = d->in_h;
   p.in_w = d->in_w;
-  p.H = d->upsample ? 2 * d->in_h : d->in_h;
-  p.W = d->upsample ? 2 * d->in_w : d->in_w;
   p.res_cb1 = d->res_cbn > 0 ? d->res_cbn : (1 << 30);
   p.mask_cb0 = d->mask_cb0;
   p.mask_cb1 = d->mask_cb0 + d->mask_cbn;
@@ -309,35 +322,132 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   p.beta2 = d->beta2;
   p.mask_slope = d->mask_slope;
   p.accumulate = d->accumulate;
-  SR_CHECK_ARG((long long)p.H * p.W * 8 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) <
-                   (1ll << 31),
-               "sr_conv3x3_f32: image too large for 32-bit plane offsets");
+  p.src_mul = 1;
+  p.dst_mul = 1;
+  return SR_OK;
+}
+
+int check_sizes(const ConvParams& p, int n, const char* who) {
+  const long long blocks = p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks;
+  SR_CHECK_ARG((long long)p.oH * p.oW * 8 * blocks < (1ll << 31) && (long long)p.in_h * p.in_w * 8 * blocks < (1ll << 31),
+               "%s: image too large for 32-bit plane offsets", who);
+  SR_CHECK_ARG((long long)p.tiles_x * p.tiles_y * n < (1ll << 31), "%s: grid too large", who);
+  return SR_OK;
+}
+
+}  // namespace
+
+extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvParams p;
+  int rc = fill_common(d, &p, "sr_conv3x3_f32");
+  if (rc) return rc;
+  p.H = p.vH = p.oH = d->upsample ? 2 * d->in_h : d->in_h;
+  p.W = p.vW = p.oW = d->upsample ? 2 * d->in_w : d->in_w;
+  p.src_shift = d->upsample ? 1 : 0;
+  p.tap_oy = p.tap_ox = -1;
   const int gc = sr::conv_group_couts(d->cout);
   const int groups = ((d->cout + 31) / 32 * 32) / gc;
   constexpr int PT = 2;
   p.tiles_x = sr::cdiv(p.W, 32);
   p.tiles_y = sr::cdiv(p.H, 4 * PT);
-  SR_CHECK_ARG((long long)p.tiles_x * p.tiles_y * d->n < (1ll << 31), "sr_conv3x3_f32: grid too large");
-  if (d->out_nchw) {
-    if (d->upsample) {
-      sr::set_error("sr_conv3x3_f32: out_nchw with upsample is not instantiated");
-      return SR_EINVAL;
+  rc = check_sizes(p, d->n, "sr_conv3x3_f32");
+  if (rc) return rc;
+  if (d->out_nchw) return launch<1, PT, 3, true>(p, d->n, groups, stream, d);
+  if (gc == 64) return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
+  return launch<1, PT, 3, false>(p, d->n, groups, stream, d);
+}
+
+// 4x4 / stride 2 / pad 1 convolution (VGGStyleDiscriminator128 conv*_1, discriminator_arch.py:22-43; UNetDiscriminatorSN
+// conv1-3) as four accumulating parity passes:  Y[y][x] = sum_{ry,rx} sum_{ty,tx} W[2ty+1-ry... see pack] X[2(y+qy)+ry][..]
+// Each pass is a 2x2-tap stride-1 conv over the parity sub-image (ry,rx) of X: qy = ty + (ry ? -1 : 0), dy = 2*qy + 1 + ry.
+extern "C" int sr_conv4x4s2_f32(const sr_conv3x3_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvParams p;
+  int rc = fill_common(d, &p, "sr_conv4x4s2_f32");
+  if (rc) return rc;
+  SR_CHECK_ARG(!d->out_nchw && !d->upsample && !d->mask_src && !d->accumulate && d->in_h >= 2 && d->in_w >= 2,
+               "sr_conv4x4s2_f32: unsupported option");
+  p.H = p.oH = (d->in_h - 2) / 2 + 1;
+  p.W = p.oW = (d->in_w - 2) / 2 + 1;
+  const int gc = sr::conv_group_couts(d->cout);
+  const int groups = ((d->cout + 31) / 32 * 32) / gc;
+  constexpr int PT = 2;
+  p.tiles_x = sr::cdiv(p.W, 32);
+  p.tiles_y = sr::cdiv(p.H, 4 * PT);
+  rc = check_sizes(p, d->n, "sr_conv4x4s2_f32");
+  if (rc) return rc;
+  const size_t pass_floats = (size_t)groups * p.cin_blocks * 4 * gc * 8;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int ry = pass >> 1, rx = pass & 1;
+    ConvParams q = p;
+    q.w = d->wpacked + pass * pass_floats;
+    q.src_mul = 2;
+    q.src_oy = ry;
+    q.src_ox = rx;
+    q.vH = (d->in_h - ry + 1) / 2;
+    q.vW = (d->in_w - rx + 1) / 2;
+    q.tap_oy = ry ? -1 : 0;
+    q.tap_ox = rx ? -1 : 0;
+    q.accumulate = pass > 0;
+    q.acc_first = 1;
+    if (pass < 3) {  // bias, activation, scale and residuals belong to the completed sum
+      q.bias = nullptr;
+      q.slope = 1.f;
+      q.alpha = 1.f;
+      q.res1 = q.res2 = nullptr;
     }
-    return launch<1, PT, false, true>(p, d->n, groups, stream, d);
+    rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
+    if (rc) return rc;
   }
-  if (gc == 64) {
-    return d->upsample ? launch<2, PT, true, false>(p, d->n, groups, stream, d)
-                       : launch<2, PT, false, false>(p, d->n, groups, stream, d);
+  return SR_OK;
+}
+
+// Data gradient of the 4x4/s2 conv: dX[2a+py][2b+px] = sum over the two taps per axis of matching parity.
+// d->in = dY (in_h x in_w), d->out = dX (out_h x out_w, required), d->wpacked from sr_conv4x4s2_pack_f32(mode 1),
+// d->cout = channels of dX.
+extern "C" int sr_conv4x4s2_dgrad_f32(const sr_conv3x3_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvParams p;
+  int rc = fill_common(d, &p, "sr_conv4x4s2_dgrad_f32");
+  if (rc) return rc;
+  SR_CHECK_ARG(!d->out_nchw && !d->upsample && d->out_h > 0 && d->out_w > 0, "sr_conv4x4s2_dgrad_f32: out_h/out_w required");
+  SR_CHECK_ARG((d->out_h - 2) / 2 + 1 == d->in_h && (d->out_w - 2) / 2 + 1 == d->in_w,
+               "sr_conv4x4s2_dgrad_f32: dY %dx%d does not match dX %dx%d", d->in_h, d->in_w, d->out_h, d->out_w);
+  p.oH = d->out_h;
+  p.oW = d->out_w;
+  p.vH = d->in_h;
+  p.vW = d->in_w;
+  const int gc = sr::conv_group_couts(d->cout);
+  const int groups = ((d->cout + 31) / 32 * 32) / gc;
+  constexpr int PT = 2;
+  const size_t pass_floats = (size_t)groups * p.cin_blocks * 4 * gc * 8;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int py = pass >> 1, px = pass & 1;
+    ConvParams q = p;
+    q.w = d->wpacked + pass * pass_floats;
+    q.H = (d->out_h - py + 1) / 2;
+    q.W = (d->out_w - px + 1) / 2;
+    q.tiles_x = sr::cdiv(q.W, 32);
+    q.tiles_y = sr::cdiv(q.H, 4 * PT);
+    q.dst_mul = 2;
+    q.dst_oy = py;
+    q.dst_ox = px;
+    q.tap_oy = py ? 0 : -1;
+    q.tap_ox = px ? 0 : -1;
+    rc = check_sizes(q, d->n, "sr_conv4x4s2_dgrad_f32");
+    if (rc) return rc;
+    rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
+    if (rc) return rc;
   }
-  return d->upsample ? launch<1, PT, true, false>(p, d->n, groups, stream, d)
-                     : launch<1, PT, false, false>(p, d->n, groups, stream, d);
+  return SR_OK;
 }
 
 extern "C" const char* sr_kernel_name(int id) {
   static const char* names[8] = {
-      "conv3x3_f32_kernelILi1ELi2ELb0ELb0E", "conv3x3_f32_kernelILi1ELi2ELb0ELb1E", "conv3x3_f32_kernelILi1ELi2ELb1ELb0E",
-      "conv3x3_f32_kernelILi1ELi2ELb1ELb1E", "conv3x3_f32_kernelILi2ELi2ELb0ELb0E", "conv3x3_f32_kernelILi2ELi2ELb0ELb1E",
-      "conv3x3_f32_kernelILi2ELi2ELb1ELb0E", "conv3x3_f32_kernelILi2ELi2ELb1ELb1E"};
+      "conv_f32_kernelILi1ELi2ELi3ELb0E", "conv_f32_kernelILi1ELi2ELi3ELb1E", "conv_f32_kernelILi1ELi2ELi2ELb0E",
+      "conv_f32_kernelILi1ELi2ELi2ELb1E", "conv_f32_kernelILi2ELi2ELi3ELb0E", "conv_f32_kernelILi2ELi2ELi3ELb1E",
+      "conv_f32_kernelILi2ELi2ELi2ELb0E", "conv_f32_kernelILi2ELi2ELi2ELb1E"};
   static const char* wnames[5] = {"wgrad3x3_f32_kernelILi1ELi1ELi1E", "wgrad3x3_f32_kernelILi1ELi2ELi1E",
                                   "wgrad3x3_f32_kernelILi1ELi4ELi1E", "wgrad3x3_f32_kernelILi2ELi2ELi1E",
                                   "wgrad3x3_f32_kernelILi2ELi1ELi1E"};

@@ -238,3 +238,60 @@ extern "C" int sr_cb8_axpby_f32(float* dst, int64_t dst_img_stride, const float*
   SR_CHECK_LAUNCH("cb8_axpby");
   return SR_OK;
 }
+
+// ---- 4x4 / stride-2 conv weights: four parity-pass images of a 2x2 tap grid -------------------------
+namespace {
+// thread per (co, ci, dy, dx) of the OIHW [cout][cin][4][4] weight.
+//   mode 0 (forward):  pass = (ry, rx) with ry = 1 - (dy & 1), tap ty = dy >> 1          (see sr_conv4x4s2_f32)
+//   mode 1 (dgrad):    pass = (py, px) with py = 1 - (dy & 1), tap ty = (3 - dy) >> 1, channel roles swapped
+__global__ void pack_w4_kernel(const float* __restrict__ w, int cout, int cin, int cin_pad, int mode,
+                               float* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * cin * 16) return;
+  const int dx = i & 3, dy = (i >> 2) & 3;
+  const int ci = (i >> 4) % cin, co = i / (16 * cin);
+  const float val = w[i];
+  const int pass = (1 - (dy & 1)) * 2 + (1 - (dx & 1));
+  if (mode == 0) {
+    const int tap = (dy >> 1) * 2 + (dx >> 1);
+    const int gc = (((cout + 31) / 32 * 32) % 64 == 0) ? 64 : 32;
+    const int G = ((cout + 31) / 32 * 32) / gc, cbs = cin_pad / 8;
+    const int g = co / gc, col = co % gc;
+    wp[(((((long long)pass * G + g) * cbs + (ci >> 3)) * 4 + tap) * gc + col) * 8 + (ci & 7)] = val;
+  } else {
+    const int tap = ((3 - dy) >> 1) * 2 + ((3 - dx) >> 1);
+    const int oc = cin_pad;
+    const int gc = (((oc + 31) / 32 * 32) % 64 == 0) ? 64 : 32;
+    const int G = ((oc + 31) / 32 * 32) / gc, cbs = (cout + 7) / 8;
+    const int g = ci / gc, col = ci % gc;
+    wp[(((((long long)pass * G + g) * cbs + (co >> 3)) * 4 + tap) * gc + col) * 8 + (co & 7)] = val;
+  }
+}
+}  // namespace
+
+extern "C" size_t sr_conv4x4s2_packed_weight_floats(int cout, int cin, int mode) {
+  const int cin_pad = (cin + 7) / 8 * 8;
+  if (mode == 0) return (size_t)((cout + 31) / 32 * 32) * cin_pad * 16;
+  return (size_t)((cin_pad + 31) / 32 * 32) * ((cout + 7) / 8 * 8) * 16;
+}
+
+extern "C" int sr_conv4x4s2_pack_f32(const float* weight, const float* bias, int cout, int cin, int mode, float* wpacked,
+                                     float* bpacked, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(weight && wpacked && cout > 0 && cin > 0 && (mode == 0 || mode == 1), "sr_conv4x4s2_pack_f32: bad argument");
+  const size_t wfloats = sr_conv4x4s2_packed_weight_floats(cout, cin, mode);
+  if (hipMemsetAsync(wpacked, 0, wfloats * sizeof(float), stream) != hipSuccess) {
+    sr::set_error("sr_conv4x4s2_pack_f32: memset failed");
+    return SR_ELAUNCH;
+  }
+  const int total = cout * cin * 16;
+  hipLaunchKernelGGL(pack_w4_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, cout, cin,
+                     (cin + 7) / 8 * 8, mode, wpacked);
+  SR_CHECK_LAUNCH("pack_w4");
+  if (bpacked && mode == 0) {
+    const int cp = (int)sr_conv3x3_packed_bias_floats(cout);
+    hipLaunchKernelGGL(pack_b_kernel, dim3((cp + 255) / 256), dim3(256), 0, stream, bias, cout, cp, bpacked);
+    SR_CHECK_LAUNCH("pack_b");
+  }
+  return SR_OK;
+}

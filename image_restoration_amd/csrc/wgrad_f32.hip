@@ -39,6 +39,9 @@ struct WgradParams {
   int strips;       // column strips per image = ceil(W/32)
   int rows_per_wg;  // multiple of R
   int row_splits;   // ceil(H / rows_per_wg)
+  // source map (same convention as the forward kernel, conv_f32.hip): tap (ty,tx) of output pixel (y,x) reads
+  // virtual pixel (y+tap_oy+ty, x+tap_ox+tx), valid in [0,vH)x[0,vW), real = ((v*src_mul)>>src_shift)+src_o.
+  int vH, vW, src_mul, src_shift, src_oy, src_ox, tap_oy, tap_ox;
 };
 
 __device__ __forceinline__ void glds16w(const float* src, char* lds_dst) {
@@ -48,20 +51,21 @@ __device__ __forceinline__ void glds16w(const float* src, char* lds_dst) {
 
 // R = output rows per step.  R == KS: the KS waves of a pair split the step's rows;
 // R == 1 (with KS > 1): they split the 16 pixel-pair k-steps of the single row.
-template <int CT, int IT, int R, bool UPS>
-__global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) {
+template <int CT, int IT, int R, int KT>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = CT * IT, KS = 4 / P;
   static_assert(R == KS || R == 1, "row split or k-step split");
   constexpr bool ROWSPLIT = (R == KS);
   constexpr int SN = ROWSPLIT ? 16 : 16 / KS;  // k-steps per wave per row
   constexpr int XCH = 32 * IT, YCH = 32 * CT;
-  constexpr int XPIECES = 34 * (XCH / 4);                      // 16-byte pieces of one X row
+  constexpr int XPIX = 32 + KT - 1;                            // pixels of one X row (with halo)
+  constexpr int XPIECES = XPIX * (XCH / 4);                    // 16-byte pieces of one X row
   constexpr int XUNITS = (XPIECES + 63) / 64;                  // wave-instructions per X row
   constexpr int XROWB = XUNITS * 1024;                         // bytes per X ring slot
   constexpr int YUNITS = (32 * (YCH / 4)) / 64;                // = 4*CT
   constexpr int YROWB = YUNITS * 1024;
-  constexpr int NXR = 2 * R + 2, NYR = 2 * R;                  // ring depths (rows)
+  constexpr int NXR = 2 * R + KT - 1, NYR = 2 * R;             // ring depths (rows)
   constexpr int XRING = NXR * XROWB;
   constexpr int UNITS_PER_STEP = R * (XUNITS + YUNITS);
   constexpr int UPW = (UNITS_PER_STEP + 3) / 4;                // units per wave per step
@@ -86,9 +90,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
   char* xring = smem;
   char* yring = smem + XRING;
 
-  // Stage the rows a step needs: X rows [yx, yx+R) into their ring slots, dY rows [yy, yy+R).
-  // Units (1 KiB wave-instructions) are dealt round-robin to the 4 waves.
-  auto stage = [&](int yx, int yy, bool with_dy) {
+  // Stage the rows a step needs: X tap-rows u in [ux, ux+R) (virtual row u + tap_oy, ring slot u % NXR) and
+  // dY rows [yy, yy+R).  Units (1 KiB wave-instructions) are dealt round-robin to the 4 waves.
+  auto stage = [&](int ux, int yy, bool with_dy) {
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
       const int u = uu * 4 + wave;
@@ -96,15 +100,16 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
       const int r = u / (XUNITS + YUNITS), v = u % (XUNITS + YUNITS);
       if (v >= XUNITS && !with_dy) continue;
       if (v < XUNITS) {
-        const int y = yx + r;  // output-space row of this X row; may be -1 or >= H (zero row)
+        const int u = ux + r;
+        const int vy = u + p.tap_oy;  // virtual source row; outside [0, vH) = zero row
         const int q = v * 64 + lane;
         const int pix = q / (XCH / 4), c4 = q % (XCH / 4);
         const int cb = p.cin_tile0 * 4 + (c4 >> 1);
-        const int gx = x0 - 1 + pix;
-        const bool ok = (q < XPIECES) && y >= 0 && y < p.H && gx >= 0 && gx < p.W && cb < p.cin_blocks;
-        const int sy = UPS ? (y >> 1) : y, sx = UPS ? (gx >> 1) : gx;
+        const int gx = x0 + p.tap_ox + pix;
+        const bool ok = (q < XPIECES) && vy >= 0 && vy < p.vH && gx >= 0 && gx < p.vW && cb < p.cin_blocks;
+        const int sy = ((vy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
         const float* src = ok ? xn + cb * xplane + ((long long)sy * p.x_w + sx) * 8 + (c4 & 1) * 4 : g_zero_line_w;
-        const int slot = (y + 1 + NXR) % NXR;
+        const int slot = u % NXR;
         glds16w(src, xring + slot * XROWB + v * 1024);
       } else {
         const int vy = v - XUNITS;
@@ -121,9 +126,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[KT * KT];
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < KT * KT; ++a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
   float bsum = 0.f;
@@ -131,31 +136,31 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
   const int a_lane = (h * YCH + ct * 32 + j) * 4;  // byte offset of A operand: pixel h of the pair, this lane's cout
   const int b_lane = (h * XCH + it * 32 + j) * 4;  // byte offset of B operand: pixel h (+dx), this lane's cin
 
-  // Invariant at the top of step y: X rows y-1 .. y+R and dY rows y .. y+R-1 are in LDS.
-  // During step y the rows of step y+R arrive: X rows y+R+1 .. y+2R, dY rows y+R .. y+2R-1.
-  // Live X rows y-1 .. y+2R are 2R+2 consecutive rows = distinct ring slots; dY rows y .. y+2R-1 likewise.
-  stage(y_begin - 1, y_begin, true);
-  for (int r0 = y_begin - 1 + R; r0 <= y_begin + R; r0 += R) stage(r0, 0, false);
+  // Invariant at the top of step y (tap-rows u = y + ty): X rows u in [y, y+KT-1+R) and dY rows [y, y+R) are in LDS.
+  // During step y the rows of step y+R arrive: u in [y+KT-1+R, y+KT-1+2R), dY rows [y+R, y+2R).
+  // Live tap-rows [y, y+KT-1+2R) are NXR consecutive rows = distinct ring slots; dY rows [y, y+2R) likewise.
+  stage(y_begin, y_begin, true);
+  for (int u0 = y_begin + R; u0 < y_begin + KT - 1 + R; u0 += R) stage(u0, 0, false);
   __syncthreads();
   for (int y = y_begin; y < y_end; y += R) {
-    stage(y + R + 1, y + R, true);
+    stage(y + KT - 1 + R, y + R, true);
     const int row = ROWSPLIT ? y + ks : y;
     const int s0 = ROWSPLIT ? 0 : ks * SN;
     if (row < y_end) {
       const char* ya = yring + (row % NYR) * YROWB + a_lane + s0 * 2 * YCH * 4;
-      const char* xb[3];
+      const char* xb[KT];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) xb[dy] = xring + ((row + dy) % NXR) * XROWB + b_lane + s0 * 2 * XCH * 4;
+      for (int dy = 0; dy < KT; ++dy) xb[dy] = xring + ((row + dy) % NXR) * XROWB + b_lane + s0 * 2 * XCH * 4;
 #pragma unroll
       for (int s = 0; s < SN; ++s) {
         const float a = *(const float*)(ya + s * 2 * YCH * 4);
         bsum += a;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < KT; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
+          for (int dx = 0; dx < KT; ++dx) {
             const float b = *(const float*)(xb[dy] + (s * 2 + dx) * XCH * 4);
-            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dy * 3 + dx], 0, 0, 0);
+            acc[dy * KT + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dy * KT + dx], 0, 0, 0);
           }
       }
     }
@@ -165,9 +170,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_f32_kernel(const WgradParams p) 
   // write this wave's partial tile:  slab[split][pair][tap][g][lane][4]
   const int pair = ct * IT + it;
   const long long split = (long long)blockIdx.x * KS + ks;
-  float* dst = p.slab + ((split * P + pair) * 9) * 1024 + lane * 4;
+  float* dst = p.slab + ((split * P + pair) * (KT * KT)) * 1024 + lane * 4;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int tap = 0; tap < KT * KT; ++tap)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
@@ -242,6 +247,8 @@ struct ReduceParams {
   float* dw;           // [cout][cin][3][3]
   float* db;           // [cout] or null
   int sch, splits, P, IT, CT;
+  int ntap, ks;                // taps per pair (ks*ks) and tap-grid width
+  int kdim, t_mul, dy_off, dx_off;  // kernel position of tap (ty,tx): (ty*t_mul+dy_off, tx*t_mul+dx_off) in a kdim x kdim kernel
   int cin_tile0, cout_tile0;
   int cout, cin, first_seg, seg;  // reference channel counts and concat segmentation
   float scale;
@@ -250,12 +257,12 @@ struct ReduceParams {
 
 __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int per_split = p.P * 9 * 1024;
+  const int per_split = p.P * p.ntap * 1024;
   if (idx < per_split) {
     float s = 0.f;
     for (int k = 0; k < p.sch; ++k) s += p.part[(long long)k * per_split + idx];
     const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3;
-    const int tap = (idx >> 10) % 9, pair = idx / (9 * 1024);
+    const int tap = (idx >> 10) % p.ntap, pair = idx / (p.ntap * 1024);
     const int ct = pair / p.IT, it = pair % p.IT;
     const int co = (p.cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5) + e;
     const int pos = (p.cin_tile0 + it) * 32 + (lane & 31);
@@ -270,7 +277,8 @@ __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
       if (o < p.seg) ci = p.first_seg + sgi * p.seg + o;
     }
     if (co < p.cout && ci >= 0 && ci < p.cin) {
-      float* o = p.dw + ((long long)co * p.cin + ci) * 9 + tap;
+      const int ky = (tap / p.ks) * p.t_mul + p.dy_off, kx = (tap % p.ks) * p.t_mul + p.dx_off;
+      float* o = p.dw + (((long long)co * p.cin + ci) * p.kdim + ky) * p.kdim + kx;
       *o = p.accumulate ? *o + s * p.scale : s * p.scale;
     }
   }
@@ -282,17 +290,21 @@ __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
   }
 }
 
-template <int CT, int IT, int R>
+template <int CT, int IT, int R, int KS>
 constexpr int wgrad_lds_bytes() {
-  constexpr int XUNITS = (34 * (32 * IT / 4) + 63) / 64, YUNITS = 4 * CT;
-  return (2 * R + 2) * XUNITS * 1024 + 2 * R * YUNITS * 1024;
+  constexpr int XUNITS = ((32 + KS - 1) * (32 * IT / 4) + 63) / 64, YUNITS = 4 * CT;
+  return (2 * R + KS - 1) * XUNITS * 1024 + 2 * R * YUNITS * 1024;
 }
 
-template <int CT, int IT, int R>
+struct TapMap {
+  int kdim, t_mul, dy_off, dx_off;
+};
+
+template <int CT, int IT, int R, int KT>
 int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, float* slab, float* bslab,
-                 bool want_bias, hipStream_t stream) {
-  constexpr int P = CT * IT, KS = 4 / P;
-  constexpr int lds = wgrad_lds_bytes<CT, IT, R>();
+                 bool want_bias, const TapMap& tm, hipStream_t stream) {
+  constexpr int P = CT * IT, KS = 4 / P, NT = KT * KT;
+  constexpr int lds = wgrad_lds_bytes<CT, IT, R, KT>();
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
   // rows per workgroup: aim at >= 512 workgroups (2 per CU), multiple of R, at least 4R rows to amortise the prologue
@@ -304,22 +316,22 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   p.row_splits = sr::cdiv(p.H, rows);
   const long long nwg = strips_total * p.row_splits;
   const long long splits = nwg * KS;
-  if ((size_t)splits * P * 9 * 1024 * sizeof(float) > d->slab_bytes ||
+  if ((size_t)splits * P * NT * 1024 * sizeof(float) > d->slab_bytes ||
       (size_t)splits * CT * 32 * sizeof(float) > d->slab_bytes / 63) {
     sr::set_error("sr_conv3x3_wgrad_f32: slab %zu B too small (need %zu B)", d->slab_bytes,
-                  (size_t)splits * P * 9 * 1024 * sizeof(float));
+                  (size_t)splits * P * NT * 1024 * sizeof(float));
     return SR_ENOSPACE;
   }
   p.slab = slab;
   p.bslab = want_bias ? bslab : nullptr;
-  auto kern = d->upsample ? wgrad3x3_f32_kernel<CT, IT, R, true> : wgrad3x3_f32_kernel<CT, IT, R, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[d->upsample ? 1 : 0]) {
+  auto kern = wgrad_f32_kernel<CT, IT, R, KT>;
+  static bool attr_set = false;
+  if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       sr::set_error("wgrad: hipFuncSetAttribute(%d) failed", lds);
       return SR_ELAUNCH;
     }
-    attr_set[d->upsample ? 1 : 0] = true;
+    attr_set = true;
   }
   const bool prof = sr::prof_on();
   if (prof) {
@@ -332,7 +344,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
     r.w = p.W;
     const double px = (double)d->n * p.H * p.W;
     const int cin_eff = min(32 * IT, d->cin_pad - 32 * cin_tile0), cout_eff = min(32 * CT, d->cout - 32 * cout_tile0);
-    r.flops = 2.0 * 9.0 * cin_eff * cout_eff * px;
+    r.flops = 2.0 * NT * cin_eff * cout_eff * px;
     r.bytes = 4.0 * px * (cin_eff + cout_eff);
     sr::prof_begin(stream, r);
   }
@@ -340,7 +352,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("wgrad3x3_f32 launch");
   // stage 1 partials live behind the bias slab
-  const int e4 = P * 9 * 256;
+  const int e4 = P * NT * 256;
   int sch = (int)((splits + 63) / 64);
   if (sch > 64) sch = 64;
   const int chunk = (int)((splits + sch - 1) / sch);
@@ -360,6 +372,12 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   rp.P = P;
   rp.IT = IT;
   rp.CT = CT;
+  rp.ntap = NT;
+  rp.ks = KT;
+  rp.kdim = tm.kdim;
+  rp.t_mul = tm.t_mul;
+  rp.dy_off = tm.dy_off;
+  rp.dx_off = tm.dx_off;
   rp.cin_tile0 = cin_tile0;
   rp.cout_tile0 = cout_tile0;
   rp.cout = d->cout;
@@ -368,7 +386,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   rp.seg = d->seg;
   rp.scale = d->scale;
   rp.accumulate = d->accumulate;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((P * 9 * 1024 + 255) / 256), dim3(256), 0, stream, rp);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((P * NT * 1024 + 255) / 256), dim3(256), 0, stream, rp);
   SR_CHECK_LAUNCH("wgrad_reduce2 launch");
   return SR_OK;
 }
@@ -386,67 +404,120 @@ extern "C" size_t sr_conv3x3_wgrad_slab_bytes(int n, int h, int w) {
   return (wbytes + wbytes / 32 + 2 * part_bytes + 4096) / 256 * 256;
 }
 
-extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(d && d->x && d->dy && d->dweight && d->slab, "sr_conv3x3_wgrad_f32: null argument");
-  SR_CHECK_ARG(d->cout > 0 && d->cin > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_wgrad_f32: bad shape");
-  const int cin_pad = sr_conv3x3_cin_pad(d->cin, d->first_seg, d->seg);
-  SR_CHECK_ARG(cin_pad > 0 && cin_pad == d->cin_pad, "sr_conv3x3_wgrad_f32: cin_pad=%d does not match cin=%d/%d/%d",
-               d->cin_pad, d->cin, d->first_seg, d->seg);
-  SR_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->slab) % 16 == 0,
-               "sr_conv3x3_wgrad_f32: pointers must be 16-byte aligned");
-  WgradParams p = {};
-  p.x = d->x;
-  p.dy = d->dy;
-  p.x_ns = d->x_img_stride;
-  p.dy_ns = d->dy_img_stride;
-  p.x_h = d->in_h;
-  p.x_w = d->in_w;
-  p.H = d->upsample ? 2 * d->in_h : d->in_h;
-  p.W = d->upsample ? 2 * d->in_w : d->in_w;
-  p.cin_blocks = cin_pad / 8;
-  p.cout_blocks = (d->cout + 7) / 8;
-  p.strips = sr::cdiv(p.W, 32);
+namespace {
+
+// Walks the (cout tile, cin tile) grid in workgroup-sized groups (2x2, 1x4, 1x2, 2x1, 1x1) for one tap grid.
+template <int KT>
+int run_groups(const sr_conv3x3_wgrad_desc* d, const WgradParams& p, int cin_pad, const TapMap& tm, bool want_bias,
+               hipStream_t stream) {
   const int cts = sr::cdiv(d->cout, 32), its = sr::cdiv(cin_pad, 32);
-  // bias slab sits behind the weight slab region
   const size_t part_bytes = (size_t)64 * 4 * 9 * 1024 * sizeof(float) + 64 * 64 * sizeof(float) + 4096;
-  SR_CHECK_ARG(d->slab_bytes > 2 * part_bytes, "sr_conv3x3_wgrad_f32: slab too small");
+  SR_CHECK_ARG(d->slab_bytes > 2 * part_bytes, "sr_conv_wgrad: slab too small");
   const size_t wslab_bytes = (d->slab_bytes - part_bytes) / 64 * 63 / 256 * 256;
   float* slab = (float*)d->slab;
   float* bslab = (float*)((char*)d->slab + wslab_bytes);
   sr_conv3x3_wgrad_desc dd = *d;
   dd.slab_bytes = wslab_bytes;
-  // Walk the (cout tile, cin tile) grid in workgroup-sized groups: 2x2, 1x4, 1x2, 2x1, 1x1.
   for (int c0 = 0; c0 < cts;) {
     const int cn = (cts - c0 >= 2) ? 2 : 1;
     for (int i0 = 0; i0 < its;) {
       const int left = its - i0;
-      const bool bias = d->dbias != nullptr && i0 == 0;
+      const bool bias = want_bias && d->dbias != nullptr && i0 == 0;
       int rc, in;
       if (cn == 2) {
         if (left >= 2) {
           in = 2;
-          rc = launch_group<2, 2, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+          rc = launch_group<2, 2, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
         } else {
           in = 1;
-          rc = launch_group<2, 1, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+          rc = launch_group<2, 1, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
         }
       } else {
         if (left >= 4) {
           in = 4;
-          rc = launch_group<1, 4, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+          rc = launch_group<1, 4, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
         } else if (left >= 2) {
           in = 2;
-          rc = launch_group<1, 2, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+          rc = launch_group<1, 2, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
         } else {
           in = 1;
-          rc = launch_group<1, 1, 1>(&dd, p, c0, i0, slab, bslab, bias, stream);
+          rc = launch_group<1, 1, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
         }
       }
       if (rc) return rc;
       i0 += in;
     }
     c0 += cn;
+  }
+  return SR_OK;
+}
+
+int fill_wgrad(const sr_conv3x3_wgrad_desc* d, WgradParams* pp, const char* who) {
+  SR_CHECK_ARG(d && d->x && d->dy && d->dweight && d->slab, "%s: null argument", who);
+  SR_CHECK_ARG(d->cout > 0 && d->cin > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "%s: bad shape", who);
+  SR_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->slab) % 16 == 0, "%s: pointers must be 16-byte aligned",
+               who);
+  WgradParams& p = *pp;
+  p = WgradParams{};
+  p.x = d->x;
+  p.dy = d->dy;
+  p.x_ns = d->x_img_stride;
+  p.dy_ns = d->dy_img_stride;
+  p.x_h = d->in_h;
+  p.x_w = d->in_w;
+  p.cout_blocks = (d->cout + 7) / 8;
+  p.src_mul = 1;
+  return SR_OK;
+}
+
+}  // namespace
+
+extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradParams p;
+  int rc = fill_wgrad(d, &p, "sr_conv3x3_wgrad_f32");
+  if (rc) return rc;
+  const int cin_pad = sr_conv3x3_cin_pad(d->cin, d->first_seg, d->seg);
+  SR_CHECK_ARG(cin_pad > 0 && cin_pad == d->cin_pad, "sr_conv3x3_wgrad_f32: cin_pad=%d does not match cin=%d/%d/%d",
+               d->cin_pad, d->cin, d->first_seg, d->seg);
+  p.H = p.vH = d->upsample ? 2 * d->in_h : d->in_h;
+  p.W = p.vW = d->upsample ? 2 * d->in_w : d->in_w;
+  p.src_shift = d->upsample ? 1 : 0;
+  p.tap_oy = p.tap_ox = -1;
+  p.cin_blocks = cin_pad / 8;
+  p.strips = sr::cdiv(p.W, 32);
+  const TapMap tm = {3, 1, 0, 0};
+  return run_groups<3>(d, p, cin_pad, tm, true, stream);
+}
+
+// Weight gradient of the 4x4/s2 conv as four parity passes (2x2 taps over the parity sub-image of X), each
+// scattering its 2x2 taps into the [cout][cin][4][4] gradient:  dy = 2*ty + 1 - ry.
+extern "C" int sr_conv4x4s2_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradParams p;
+  int rc = fill_wgrad(d, &p, "sr_conv4x4s2_wgrad_f32");
+  if (rc) return rc;
+  SR_CHECK_ARG(!d->upsample && d->seg == 0 && d->first_seg == d->cin && d->in_h >= 2 && d->in_w >= 2,
+               "sr_conv4x4s2_wgrad_f32: unsupported option");
+  const int cin_pad = (d->cin + 7) / 8 * 8;
+  SR_CHECK_ARG(cin_pad == d->cin_pad, "sr_conv4x4s2_wgrad_f32: cin_pad mismatch");
+  p.H = (d->in_h - 2) / 2 + 1;
+  p.W = (d->in_w - 2) / 2 + 1;
+  p.cin_blocks = cin_pad / 8;
+  p.strips = sr::cdiv(p.W, 32);
+  p.src_mul = 2;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int ry = pass >> 1, rx = pass & 1;
+    WgradParams q = p;
+    q.src_oy = ry;
+    q.src_ox = rx;
+    q.vH = (d->in_h - ry + 1) / 2;
+    q.vW = (d->in_w - rx + 1) / 2;
+    q.tap_oy = ry ? -1 : 0;
+    q.tap_ox = rx ? -1 : 0;
+    const TapMap tm = {4, 2, 1 - ry, 1 - rx};
+    rc = run_groups<2>(d, q, cin_pad, tm, pass == 0, stream);
+    if (rc) return rc;
   }
   return SR_OK;
 }

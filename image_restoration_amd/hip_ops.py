@@ -193,3 +193,90 @@ def cb8_axpby(dst, src, a=1.0, b=1.0):
         _lib.check(lib.sr_cb8_axpby_f32(dst.ptr, dst.img_stride, src.ptr, src.img_stride, a, b, dst.n, dst.cbn, dst.h,
                                         dst.w, _stream(dst.device)), 'sr_cb8_axpby_f32')
     return dst
+
+
+class PackedConv4x4s2:
+    """Parity-pass weight images of a 4x4 / stride 2 / pad 1 conv (sr_conv4x4s2_pack_f32); mode 1 = data gradient."""
+
+    def __init__(self, weight, bias=None, mode=0):
+        _need_cuda(weight, 'PackedConv4x4s2')
+        lib = _lib.load()
+        weight = weight.detach().contiguous().float()
+        cout, cin = weight.shape[:2]
+        assert weight.shape[2:] == (4, 4)
+        self.mode, self.conv_cout, self.conv_cin = mode, cout, cin
+        cin_pad = (cin + 7) // 8 * 8
+        if mode == 0:
+            self.cout, self.src_channels = cout, cin_pad
+        else:
+            self.cout, self.src_channels = cin_pad, (cout + 7) // 8 * 8
+        dev = weight.device
+        self.w = torch.empty(lib.sr_conv4x4s2_packed_weight_floats(cout, cin, mode), dtype=torch.float32, device=dev)
+        self.b = None
+        if mode == 0 and bias is not None:
+            bias = bias.detach().contiguous().float()
+            self.b = torch.empty(lib.sr_conv3x3_packed_bias_floats(cout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_conv4x4s2_pack_f32(weight.data_ptr(), bias.data_ptr() if self.b is not None else None,
+                                                 cout, cin, mode, self.w.data_ptr(),
+                                                 self.b.data_ptr() if self.b is not None else None, _stream(dev)),
+                       'sr_conv4x4s2_pack_f32')
+
+
+def conv4x4s2(src, pc, out=None, *, act_slope=1.0, alpha=1.0):
+    """Forward 4x4/s2/p1 conv (+bias, LeakyReLU): four accumulating parity passes of sr_conv4x4s2_f32."""
+    lib = _lib.load()
+    assert pc.mode == 0 and src.channels == pc.src_channels
+    H, W = (src.h - 2) // 2 + 1, (src.w - 2) // 2 + 1
+    if out is None:
+        out = CB8.empty(src.n, pc.cout, H, W, src.device)
+    d = _lib.ConvDesc()
+    d.in_, d.in_img_stride, d.cin_pad, d.in_h, d.in_w = src.ptr, src.img_stride, pc.src_channels, src.h, src.w
+    d.wpacked, d.bpacked, d.cout = pc.w.data_ptr(), (pc.b.data_ptr() if pc.b is not None else None), pc.cout
+    d.out, d.out_img_stride, d.n, d.act_slope, d.alpha = out.ptr, out.img_stride, src.n, act_slope, alpha
+    with torch.cuda.device(src.device):
+        _lib.check(lib.sr_conv4x4s2_f32(C.byref(d), _stream(src.device)), 'sr_conv4x4s2_f32')
+    return out
+
+
+def conv4x4s2_dgrad(dy, pc, out_h, out_w, out=None, *, alpha=1.0, accumulate=False, mask=None, mask_cb0=0,
+                    mask_slope=0.2):
+    """dX of the 4x4/s2 conv from dY (sr_conv4x4s2_dgrad_f32)."""
+    lib = _lib.load()
+    assert pc.mode == 1 and dy.channels == pc.src_channels
+    if out is None:
+        out = CB8.empty(dy.n, pc.cout, out_h, out_w, dy.device)
+    d = _lib.ConvDesc()
+    d.in_, d.in_img_stride, d.cin_pad, d.in_h, d.in_w = dy.ptr, dy.img_stride, pc.src_channels, dy.h, dy.w
+    d.wpacked, d.cout = pc.w.data_ptr(), pc.cout
+    d.out, d.out_img_stride, d.out_h, d.out_w = out.ptr, out.img_stride, out_h, out_w
+    d.n, d.act_slope, d.alpha, d.accumulate = dy.n, 1.0, alpha, int(accumulate)
+    if mask is not None:
+        d.mask_src, d.mask_img_stride, d.mask_cb0, d.mask_cbn, d.mask_slope = (mask.ptr, mask.img_stride, mask_cb0,
+                                                                               mask.cbn, mask_slope)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.sr_conv4x4s2_dgrad_f32(C.byref(d), _stream(dy.device)), 'sr_conv4x4s2_dgrad_f32')
+    return out
+
+
+def conv4x4s2_wgrad(src, dy, cout, cin, *, scale=1.0, want_bias=False):
+    """(dweight [cout,cin,4,4], dbias) of the 4x4/s2 conv (sr_conv4x4s2_wgrad_f32)."""
+    lib = _lib.load()
+    cin_pad = (cin + 7) // 8 * 8
+    assert src.channels == cin_pad
+    H, W = (src.h - 2) // 2 + 1, (src.w - 2) // 2 + 1
+    assert (dy.n, dy.h, dy.w) == (src.n, H, W)
+    dev = src.device
+    dw = torch.zeros((cout, cin, 4, 4), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = lib.sr_conv3x3_wgrad_slab_bytes(src.n, H, W)
+    slab = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d = _lib.WgradDesc()
+    d.x, d.x_img_stride, d.cin_pad, d.in_h, d.in_w, d.upsample = src.ptr, src.img_stride, cin_pad, src.h, src.w, 0
+    d.dy, d.dy_img_stride = dy.ptr, dy.img_stride
+    d.cout, d.cin, d.first_seg, d.seg, d.n, d.scale = cout, cin, cin, 0, src.n, scale
+    d.dweight, d.dbias, d.accumulate = dw.data_ptr(), (db.data_ptr() if db is not None else None), 0
+    d.slab, d.slab_bytes = slab.data_ptr(), nbytes
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_conv4x4s2_wgrad_f32(C.byref(d), _stream(dev)), 'sr_conv4x4s2_wgrad_f32')
+    return dw, db

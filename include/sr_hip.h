@@ -111,6 +111,7 @@ typedef struct sr_conv3x3_desc {
   const float* res1; int64_t res1_img_stride; float beta1;  /* CB8, same shape as out; NULL = none */
   const float* res2; int64_t res2_img_stride; float beta2;
   int res_cbn;            /* residuals apply to the first res_cbn channel blocks of out only (0 = all) */
+  int out_h, out_w;       /* destination spatial size; only sr_conv4x4s2_dgrad_f32 needs it (0 elsewhere) */
   int accumulate;         /* 1: out += result (dgrad accumulation into a concat-gradient buffer) */
   const float* mask_src;  /* optional CB8 tensor of mask_cbn channel blocks: where mask_src <= 0 the
                              final value is multiplied by mask_slope — LeakyReLU backward fused on
@@ -124,6 +125,19 @@ typedef struct sr_conv3x3_desc {
  * ResidualDenseBlock.forward (rrdbnet_arch.py:32-39), RRDB.forward (:58-63) and the
  * trunk/head convs of RRDBNet.forward (:112-118). */
 int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream);
+
+/* 4x4 / stride 2 / pad 1 convolution of the discriminators (discriminator_arch.py:22-43: conv*_1;
+ * UNetDiscriminatorSN conv1-3) and its data gradient, on the same descriptor:
+ *   sr_conv4x4s2_f32       : in [n][cin_pad][in_h][in_w] -> out [n][cout][in_h/2][in_w/2]  (bias/act/alpha/res honoured)
+ *   sr_conv4x4s2_dgrad_f32 : in = dY [in_h][in_w], out = dX [out_h][out_w] (set out_h/out_w), cout = channels of dX;
+ *                            accumulate / mask_src honoured.
+ * Both run as four parity passes of a 2x2-tap MFMA conv; weights come from sr_conv4x4s2_pack_f32
+ * (weight OIHW [cout][cin][4][4]; mode 0 forward, mode 1 data gradient). */
+size_t sr_conv4x4s2_packed_weight_floats(int cout, int cin, int mode);
+int sr_conv4x4s2_pack_f32(const float* weight, const float* bias, int cout, int cin, int mode, float* wpacked,
+                          float* bpacked, void* stream);
+int sr_conv4x4s2_f32(const sr_conv3x3_desc* d, void* stream);
+int sr_conv4x4s2_dgrad_f32(const sr_conv3x3_desc* d, void* stream);
 
 /* Weight / bias gradient of the same convolution (what autograd computes for nn.Conv2d in
  * ESRGANModel.optimize_parameters' backward calls, esrgan_model.py:47,68,72):
@@ -148,6 +162,9 @@ typedef struct sr_conv3x3_wgrad_desc {
 } sr_conv3x3_wgrad_desc;
 size_t sr_conv3x3_wgrad_slab_bytes(int n, int out_h, int out_w);
 int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream);
+/* Same for the 4x4/s2 conv: dweight is [cout][cin][4][4]; x is the conv's source (in_h x in_w), dy its output
+ * gradient ((in_h-2)/2+1 rows); upsample/seg unused.  Slab size: sr_conv3x3_wgrad_slab_bytes(n, out_h, out_w). */
+int sr_conv4x4s2_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream);
 
 /* ------------------------------------------------------- whole generator ---- */
 
