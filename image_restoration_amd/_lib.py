@@ -72,6 +72,30 @@ SIGNATURES = {
     'sr_conv3x3_wgrad_slab_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_wgrad_f32': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     'sr_conv4x4s2_wgrad_f32': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    'sr_reduce_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'sr_bn_lrelu_fwd_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_bn_lrelu_bwd_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_lrelu_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    'sr_linear_fwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_void_p]),
+    'sr_linear_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_mean_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_l1_loss_fwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    'sr_l1_loss_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sr_bce_logits_fwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_bce_logits_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    'sr_fill_scaled_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    'sr_adam_step_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    'sr_axpby_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
     'sr_rrdbnet_num_params': (C.c_int, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_packed_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
@@ -86,7 +110,7 @@ SIGNATURES = {
                                                C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_rrdbnet_backward_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
-                                          C.c_size_t, C.c_void_p]),
+                                          C.c_size_t, C.c_int, C.c_void_p]),
 }
 
 

@@ -1,0 +1,96 @@
+"""VGG-style discriminator on the HIP path.
+
+Same constructor, forward contract and state_dict keys as the reference
+``basicsr/archs/discriminator_arch.py:6-72`` (conv{i}_{0,1}, bn{i}_{0,1} incl. running statistics and
+num_batches_tracked, linear1, linear2), so ``network_d: {type: VGGStyleDiscriminator128, ...}`` and saved
+``net_d_*.pth`` files drop in.  The modules hold parameters only; the arithmetic is HIP launches
+(hip_autograd.ConvFn / BNLReLUFn / LinearFn).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import _lib
+from .. import hip_autograd as A
+from ..utils.registry import ARCH_REGISTRY
+from .arch_util import Conv3x3Params
+
+
+class BatchNormParams(nn.Module):
+    """State of nn.BatchNorm2d(c, affine=True): weight, bias, running_mean, running_var, num_batches_tracked
+    (momentum 0.1, eps 1e-5 — the nn defaults the reference uses, discriminator_arch.py:23)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def apply_lrelu(self, x, slope):
+        """BatchNorm (batch statistics in train mode, running statistics in eval mode) + LeakyReLU on CB8."""
+        if self.training:
+            self.num_batches_tracked += 1
+        return A.BNLReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.momentum, self.eps, slope)
+
+    def extra_repr(self):
+        return f'{self.num_features}, eps={self.eps}, momentum={self.momentum} [HIP]'
+
+
+class LinearParams(nn.Module):
+    """weight [out, in] + bias [out] with nn.Linear's default initialisation."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features}, out_features={self.out_features} [HIP]'
+
+
+@ARCH_REGISTRY.register()
+class VGGStyleDiscriminator128(nn.Module):
+    """VGGStyleDiscriminator128(num_in_ch, num_feat): [N, num_in_ch, 128, 128] -> [N, 1] logits."""
+
+    def __init__(self, num_in_ch, num_feat):
+        super().__init__()
+        nf = num_feat
+        self.num_in_ch, self.num_feat = num_in_ch, num_feat
+        self.conv0_0 = Conv3x3Params(num_in_ch, nf, bias=True)
+        self.conv0_1 = Conv3x3Params(nf, nf, bias=False, ksize=4)
+        self.bn0_1 = BatchNormParams(nf)
+        widths = [(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)]
+        for i, (ci, co) in enumerate(widths, start=1):
+            setattr(self, f'conv{i}_0', Conv3x3Params(ci, co, bias=False))
+            setattr(self, f'bn{i}_0', BatchNormParams(co))
+            setattr(self, f'conv{i}_1', Conv3x3Params(co, co, bias=False, ksize=4))
+            setattr(self, f'bn{i}_1', BatchNormParams(co))
+        self.linear1 = LinearParams(nf * 8 * 4 * 4, 100)
+        self.linear2 = LinearParams(100, 1)
+
+    def forward(self, x):
+        assert x.size(2) == 128 and x.size(3) == 128, (f'Input spatial size must be 128x128, but received {x.size()}.')
+        if not x.is_cuda:
+            raise _lib.SrHipError('VGGStyleDiscriminator128.forward runs only on a HIP device (no CPU fallback)')
+        feat = A.ToCB8.apply(x.contiguous().float())
+        feat = A.ConvFn.apply(feat, self.conv0_0.weight, self.conv0_0.bias, 0.2)            # lrelu(conv0_0(x))
+        feat = self.bn0_1.apply_lrelu(A.ConvFn.apply(feat, self.conv0_1.weight, None, 1.0), 0.2)  # 64x64
+        for i in range(1, 5):
+            c0, b0 = getattr(self, f'conv{i}_0'), getattr(self, f'bn{i}_0')
+            c1, b1 = getattr(self, f'conv{i}_1'), getattr(self, f'bn{i}_1')
+            feat = b0.apply_lrelu(A.ConvFn.apply(feat, c0.weight, None, 1.0), 0.2)
+            feat = b1.apply_lrelu(A.ConvFn.apply(feat, c1.weight, None, 1.0), 0.2)           # 32, 16, 8, 4
+        feat = A.FromCB8.apply(feat, self.num_feat * 8)
+        feat = feat.reshape(feat.size(0), -1)                                                # view(N, -1): plain metadata
+        feat = A.LinearFn.apply(feat, self.linear1.weight, self.linear1.bias, 0.2)
+        return A.LinearFn.apply(feat, self.linear2.weight, self.linear2.bias, 1.0)

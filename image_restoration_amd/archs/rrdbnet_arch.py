@@ -67,9 +67,18 @@ class RRDBNet(nn.Module):
         self.conv_last = Conv3x3Params(num_feat, num_out_ch)
         self._packed = None       # device blob of MFMA-ready weights
         self._packed_key = None   # (data_ptr, _version) of every parameter at pack time
+        self._packed_dg = None
+        self._packed_dg_key = None
+        self._grad_sink = None    # set by optim.FlatAdam: gradients accumulate straight into its arena
         self._workspaces = {}
 
     # ------------------------------------------------------------------ HIP plumbing
+    def invalidate_packed(self):
+        """Call after parameter memory was updated behind autograd's back (fused Adam / EMA kernels write the
+        arena without bumping tensor versions)."""
+        self._packed_key = None
+        self._packed_dg_key = None
+
     def _cfg(self):
         # scale other than 1/2/4 behaves like 4 in the reference (no unshuffle, :106-111)
         s = self.scale if self.scale in (1, 2) else 4

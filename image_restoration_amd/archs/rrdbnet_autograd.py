@@ -61,17 +61,28 @@ class _RRDBNetFunction(torch.autograd.Function):
             packed_dg = net._ensure_packed_dgrad(lib, cfg, stream)
             wbytes = lib.sr_rrdbnet_backward_workspace_bytes(C.byref(cfg), n, h, w)
             ws = net._bwd_workspace(wbytes, dev)
-            grads = [torch.empty_like(p) if need else None for p, need in zip(params, need_p)]
-            # weight and bias of one conv travel together: a conv is skipped only when its weight needs no grad
-            ptrs = (C.c_void_p * len(params))(*[g.data_ptr() if g is not None else None for g in grads])
-            for i in range(0, len(params), 2):
-                if grads[i] is None and grads[i + 1] is not None:
-                    raise _lib.SrHipError('bias.requires_grad without weight.requires_grad is not supported')
+            sink = getattr(net, '_grad_sink', None)
+            if sink is not None and any(need_p):
+                # Flat-arena mode (image_restoration_amd.optim.FlatAdam): gradients are ACCUMULATED straight into
+                # the arena that is all-reduced and consumed by the fused Adam kernel; autograd sees no grads.
+                if not all(need_p):
+                    raise _lib.SrHipError('flat-arena mode needs every generator parameter to require grad')
+                grads = [None] * len(params)
+                ptrs = (C.c_void_p * len(params))(*sink.grad_ptrs)
+                accumulate = 1
+            else:
+                grads = [torch.empty_like(p) if need else None for p, need in zip(params, need_p)]
+                # weight and bias of one conv travel together: a conv is skipped only when its weight needs no grad
+                ptrs = (C.c_void_p * len(params))(*[g.data_ptr() if g is not None else None for g in grads])
+                for i in range(0, len(params), 2):
+                    if grads[i] is None and grads[i + 1] is not None:
+                        raise _lib.SrHipError('bias.requires_grad without weight.requires_grad is not supported')
+                accumulate = 0
             dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
             _lib.check(lib.sr_rrdbnet_backward_f32(C.byref(cfg), packed_dg.data_ptr(), ctx.saved.data_ptr(),
                                                    ctx.saved.numel(), dy.data_ptr(), n, h, w, ptrs,
                                                    dx.data_ptr() if dx is not None else None, ws.data_ptr(), wbytes,
-                                                   stream), 'sr_rrdbnet_backward_f32')
+                                                   accumulate, stream), 'sr_rrdbnet_backward_f32')
         ctx.saved = None
         return (None, dx) + tuple(grads)
 

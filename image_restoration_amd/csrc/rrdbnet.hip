@@ -343,7 +343,7 @@ extern "C" int sr_rrdbnet_forward_train_f32(const sr_rrdbnet_cfg* cfg, const flo
 extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad, const void* saved,
                                        size_t saved_bytes, const float* dy, int n, int h_in, int w_in,
                                        float* const* host_dparams, float* dx, void* workspace, size_t workspace_bytes,
-                                       void* stream_) {
+                                       int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NetPlan P;
   SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_backward_f32: bad config");
@@ -424,6 +424,7 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
     d.scale = scale;
     d.dweight = dwp;
     d.dbias = dbp;
+    d.accumulate = accumulate;
     d.slab = B.slab;
     d.slab_bytes = B.slab_bytes;
     return sr_conv3x3_wgrad_f32(&d, stream);

@@ -1,0 +1,519 @@
+// HBM-bound training ops of the ESRGAN step (everything that is not a convolution):
+//   BatchNorm2d(+LeakyReLU) forward/backward of VGGStyleDiscriminator128 (discriminator_arch.py:23-49),
+//   nn.Linear forward/backward (:45-46), L1Loss (losses.py:80-106), the relativistic vanilla GAN loss
+//   (BCEWithLogits, losses.py:379-380 under esrgan_model.py:40-41,67,71), Adam (base_model.py:78-83) and
+//   EMA (base_model.py:50-57).
+// All reductions are two-stage and deterministic (fixed grid, fixed summation order); no atomics.
+#include "sr_internal.h"
+
+namespace {
+
+constexpr int RED_SPLITS = 64;  // blocks per reduced quantity
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  // 256 threads: wave shuffle then 4 partials through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------ BatchNorm on CB8
+// per-channel sums over N*H*W of f(x): mode 0: x ; mode 1: (x-mean)^2 ; mode 2: dz (and dz*xhat) for backward.
+// grid (cblocks, RED_SPLITS), block 256.  Thread t covers float4 `half = t&1` of pixels t>>1, t>>1 + 128, ...
+struct BnRedParams {
+  const float* x;
+  const float* dy;
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  float* part;  // [cblocks][RED_SPLITS][8][2]
+  long long x_ns, dy_ns, y_ns;
+  int n, hw, mode;
+  float slope;
+};
+
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnRedParams p) {
+  __shared__ float sh[4];
+  const int cb = blockIdx.x, sp = blockIdx.y;
+  const int half = threadIdx.x & 1;
+  const long long total = (long long)p.n * p.hw;
+  float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+  if (p.mode >= 1) mu = *(const float4*)(p.mean + cb * 8 + half * 4);
+  if (p.mode == 2) is = *(const float4*)(p.invstd + cb * 8 + half * 4);
+  for (long long i = (long long)sp * 128 + (threadIdx.x >> 1); i < total; i += 128 * RED_SPLITS) {
+    const int n = (int)(i / p.hw);
+    const long long off = ((long long)cb * p.hw + (i - (long long)n * p.hw)) * 8 + half * 4;
+    const float4 xv = *(const float4*)(p.x + n * p.x_ns + off);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float ms[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+    if (p.mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += xs[e];
+    } else if (p.mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += (xs[e] - ms[e]) * (xs[e] - ms[e]);
+    } else {
+      const float4 gv = *(const float4*)(p.dy + n * p.dy_ns + off);
+      const float4 yv = *(const float4*)(p.y + n * p.y_ns + off);
+      const float gs[4] = {gv.x, gv.y, gv.z, gv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dz = ys[e] > 0.f ? gs[e] : gs[e] * p.slope;  // LeakyReLU backward from the saved output
+        a[e] += dz;
+        b[e] += dz * (xs[e] - ms[e]) * iv[e];
+      }
+    }
+  }
+  // reduce the two parities separately: even threads hold channels 0-3, odd threads 4-7
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float s0 = block_sum(half == 0 ? a[e] : 0.f, sh), s1 = block_sum(half == 1 ? a[e] : 0.f, sh);
+    const float t0 = block_sum(half == 0 ? b[e] : 0.f, sh), t1 = block_sum(half == 1 ? b[e] : 0.f, sh);
+    if (threadIdx.x == 0) {
+      float* o = p.part + (((long long)cb * RED_SPLITS + sp) * 8) * 2;
+      o[e * 2] = s0;
+      o[e * 2 + 1] = t0;
+      o[(4 + e) * 2] = s1;
+      o[(4 + e) * 2 + 1] = t1;
+    }
+  }
+}
+
+// one thread per channel: sums the partials.  which 0: mean ; 1: var -> invstd (+ running stats) ; 2: dbeta/dgamma
+__global__ void bn_finalize_kernel(const float* part, int c, int which, long long count, float eps, float momentum,
+                                   float* mean, float* invstd, float* running_mean, float* running_var, float* dgamma,
+                                   float* dbeta, const float* gamma_scale_unused) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const int cb = ch >> 3, e = ch & 7;
+  float s = 0.f, t = 0.f;
+  for (int k = 0; k < RED_SPLITS; ++k) {
+    const float* o = part + (((long long)cb * RED_SPLITS + k) * 8 + e) * 2;
+    s += o[0];
+    t += o[1];
+  }
+  if (which == 0) {
+    mean[ch] = s / (float)count;
+  } else if (which == 1) {
+    const float var = s / (float)count;  // biased, used for normalisation
+    invstd[ch] = rsqrtf(var + eps);
+    if (running_mean) {
+      // nn.BatchNorm2d: running = (1-m)*running + m*batch, with the UNBIASED variance
+      const float unbiased = count > 1 ? s / (float)(count - 1) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean[ch];
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+  } else {
+    dbeta[ch] = s;
+    dgamma[ch] = t;
+  }
+}
+
+// y = lrelu((x - mean)*invstd*gamma + beta); pad channels (>= c) are written as zero.
+__global__ void bn_lrelu_fwd_kernel(const float* __restrict__ x, long long x_ns, float* __restrict__ y, long long y_ns,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope, int c,
+                                    int cblocks, int hw, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int pix = (int)(r % hw);
+  r /= hw;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const long long off = ((long long)cb * hw + pix) * 8 + half * 4;
+  const float4 xv = *(const float4*)(x + n * x_ns + off);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = cb * 8 + half * 4 + e;
+    float v = 0.f;
+    if (ch < c) {
+      v = (xs[e] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
+      v = v > 0.f ? v : v * slope;
+    }
+    o[e] = v;
+  }
+  *(float4*)(y + n * y_ns + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// dx = gamma*invstd*(dz - [train] (dbeta + xhat*dgamma)/M),  dz = dy * lrelu'(y)
+__global__ void bn_lrelu_bwd_kernel(const float* __restrict__ x, long long x_ns, const float* __restrict__ dy,
+                                    long long dy_ns, const float* __restrict__ y, long long y_ns, float* __restrict__ dx,
+                                    long long dx_ns, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float slope, int train, float inv_count, int c,
+                                    int cblocks, int hw, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int pix = (int)(r % hw);
+  r /= hw;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const long long off = ((long long)cb * hw + pix) * 8 + half * 4;
+  const float4 xv = *(const float4*)(x + n * x_ns + off), gv = *(const float4*)(dy + n * dy_ns + off),
+               yv = *(const float4*)(y + n * y_ns + off);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = cb * 8 + half * 4 + e;
+    float v = 0.f;
+    if (ch < c) {
+      const float dz = ys[e] > 0.f ? gs[e] : gs[e] * slope;
+      const float xhat = (xs[e] - mean[ch]) * invstd[ch];
+      v = train ? gamma[ch] * invstd[ch] * (dz - (dbeta[ch] + xhat * dgamma[ch]) * inv_count)
+                : gamma[ch] * invstd[ch] * dz;
+    }
+    o[e] = v;
+  }
+  *(float4*)(dx + n * dx_ns + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// invstd from running_var for eval mode; mean = running_mean
+__global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float eps, int c, float* mean, float* invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) {
+    mean[ch] = rm[ch];
+    invstd[ch] = rsqrtf(rv[ch] + eps);
+  }
+}
+
+// ------------------------------------------------------------------ Linear (small: in <= 16K, out <= 256)
+// y[n][o] = b[o] + sum_i x[n][i] w[o][i]      grid (out, n), block 256
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int in,
+                                                         int out, float slope) {
+  __shared__ float sh[4];
+  const int o = blockIdx.x, n = blockIdx.y;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < in; i += 256) s += x[(long long)n * in + i] * w[(long long)o * in + i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    float v = s + (b ? b[o] : 0.f);
+    y[(long long)n * out + o] = v > 0.f ? v : v * slope;
+  }
+}
+// dz[n][o] = dy * lrelu'(y) (in place into dz);  dx[n][i] = sum_o dz[n][o] w[o][i]      grid (ceil(in/256), n)
+__global__ void linear_bwd_x_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
+                                    int in, int out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (i >= in) return;
+  float s = 0.f;
+  for (int o = 0; o < out; ++o) s += dz[(long long)n * out + o] * w[(long long)o * in + i];
+  dx[(long long)n * in + i] = s;
+}
+// dw[o][i] = sum_n dz[n][o] x[n][i] ; db[o] = sum_n dz[n][o]      grid (ceil(in/256), out)
+__global__ void linear_bwd_w_kernel(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dw,
+                                    float* __restrict__ db, int in, int out, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+  if (i < in) {
+    float s = 0.f;
+    for (int n = 0; n < nb; ++n) s += dz[(long long)n * out + o] * x[(long long)n * in + i];
+    dw[(long long)o * in + i] = s;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int n = 0; n < nb; ++n) s += dz[(long long)n * out + o];
+    db[o] = s;
+  }
+}
+__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz,
+                                 float slope, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// ------------------------------------------------------------------ flat reductions / losses
+// mode 0: sum x ; 1: sum |x - t| (L1) ; 2: sum softplus(sign*(x - shift)) (BCE-with-logits vs target 1: sign=-1, 0: +1)
+// mode 3: sum sigmoid-based derivative d/dx of mode 2 (for the gradient through the mean of the other logits)
+__device__ __forceinline__ float softplus(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+struct FlatRedParams {
+  const float* x;
+  const float* t;
+  const float* shift;  // device scalar or null
+  float* part;         // [RED_SPLITS*4]
+  long long n;
+  int mode;
+  float sign;
+};
+
+__global__ __launch_bounds__(256) void flat_reduce_kernel(const FlatRedParams p) {
+  __shared__ float sh[4];
+  const float shift = p.shift ? *p.shift : 0.f;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n; i += 256LL * gridDim.x) {
+    const float v = p.x[i];
+    if (p.mode == 0) s += v;
+    else if (p.mode == 1) s += fabsf(v - p.t[i]);
+    else if (p.mode == 2) s += softplus(p.sign * (v - shift));
+    else s += p.sign * sigmoidf(p.sign * (v - shift));
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) p.part[blockIdx.x] = s;
+}
+// out[0] = scale * sum(part[0..nparts))
+__global__ void flat_finalize_kernel(const float* part, int nparts, float scale, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[k];
+    out[0] = s * scale;
+  }
+}
+// L1 backward: dx = g * scale * sign(x - t)
+__global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ g,
+                              float scale, float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float d = x[i] - t[i];
+    dx[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * scale * g[0];
+  }
+}
+// BCE backward wrt x: dx = g * scale * sign*sigmoid(sign*(x-shift))
+__global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ g,
+                               float sign, float scale, float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = sign * sigmoidf(sign * (x[i] - (shift ? *shift : 0.f))) * scale * g[0];
+}
+// fill: dx[i] = scale * g[0] * s[0]   (gradient of a mean that was subtracted from every logit)
+__global__ void fill_scaled_kernel(const float* __restrict__ g, const float* __restrict__ s, float scale,
+                                   float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = scale * g[0] * s[0];
+}
+
+// ------------------------------------------------------------------ optimiser
+// torch.optim.Adam (amsgrad=False, maximize=False): g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float grad_scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i] * grad_scale;
+  const float pi = p[i];
+  if (wd != 0.f) gi += wd * pi;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+__global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = a * dst[i] + b * src[i];
+}
+
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" size_t sr_reduce_workspace_bytes(int channels) {
+  const size_t cb = (size_t)(channels + 7) / 8;
+  return (cb * RED_SPLITS * 16 + 4 * RED_SPLITS + 64) * sizeof(float);
+}
+
+extern "C" int sr_bn_lrelu_fwd_f32(const float* x, int64_t x_ns, float* y, int64_t y_ns, int n, int c, int h, int w,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int train, float momentum, float eps, float slope, float* save_mean,
+                                   float* save_invstd, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && ws && n > 0 && c > 0 && h > 0 && w > 0,
+               "sr_bn_lrelu_fwd_f32: bad argument");
+  SR_CHECK_ARG(train || (running_mean && running_var), "sr_bn_lrelu_fwd_f32: eval mode needs running statistics");
+  SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_fwd_f32: workspace too small");
+  const int cblocks = (c + 7) / 8, hw = h * w;
+  const long long count = (long long)n * hw;
+  float* part = (float*)ws;
+  if (train) {
+    BnRedParams p = {};
+    p.x = x;
+    p.x_ns = x_ns;
+    p.n = n;
+    p.hw = hw;
+    p.part = part;
+    p.mode = 0;
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(cblocks, RED_SPLITS), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 0, count, eps, momentum, save_mean,
+                       save_invstd, nullptr, nullptr, nullptr, nullptr, nullptr);
+    p.mode = 1;
+    p.mean = save_mean;
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(cblocks, RED_SPLITS), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 1, count, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var, nullptr, nullptr, nullptr);
+  } else {
+    hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(nblk(c)), dim3(256), 0, stream, running_mean, running_var, eps, c,
+                       save_mean, save_invstd);
+  }
+  const long long total = (long long)n * cblocks * hw * 2;
+  hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, x, (long long)x_ns, y, (long long)y_ns,
+                     save_mean, save_invstd, gamma, beta, slope, c, cblocks, hw, total);
+  SR_CHECK_LAUNCH("bn_lrelu_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_bn_lrelu_bwd_f32(const float* x, int64_t x_ns, const float* dy, int64_t dy_ns, const float* y,
+                                   int64_t y_ns, float* dx, int64_t dx_ns, int n, int c, int h, int w, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, int train, float slope,
+                                   float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && dy && y && dx && gamma && save_mean && save_invstd && dgamma && dbeta && ws && n > 0 && c > 0,
+               "sr_bn_lrelu_bwd_f32: bad argument");
+  SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_bwd_f32: workspace too small");
+  const int cblocks = (c + 7) / 8, hw = h * w;
+  const long long count = (long long)n * hw;
+  float* part = (float*)ws;
+  BnRedParams p = {};
+  p.x = x;
+  p.x_ns = x_ns;
+  p.dy = dy;
+  p.dy_ns = dy_ns;
+  p.y = y;
+  p.y_ns = y_ns;
+  p.mean = save_mean;
+  p.invstd = save_invstd;
+  p.n = n;
+  p.hw = hw;
+  p.part = part;
+  p.mode = 2;
+  p.slope = slope;
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cblocks, RED_SPLITS), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 2, count, 0.f, 0.f, nullptr,
+                     nullptr, nullptr, nullptr, dgamma, dbeta, nullptr);
+  const long long total = (long long)n * cblocks * hw * 2;
+  hipLaunchKernelGGL(bn_lrelu_bwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, x, (long long)x_ns, dy, (long long)dy_ns,
+                     y, (long long)y_ns, dx, (long long)dx_ns, save_mean, save_invstd, gamma, dgamma, dbeta, slope, train,
+                     1.f / (float)count, c, cblocks, hw, total);
+  SR_CHECK_LAUNCH("bn_lrelu_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_lrelu_bwd_f32(const float* dy, const float* y, float* dz, float slope, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(dy && y && dz && n > 0, "sr_lrelu_bwd_f32: bad argument");
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, y, dz, slope, (long long)n);
+  SR_CHECK_LAUNCH("lrelu_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int n, int in, int out,
+                                 float act_slope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && w && y && n > 0 && in > 0 && out > 0, "sr_linear_fwd_f32: bad argument");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(out, n), dim3(256), 0, stream, x, w, b, y, in, out, act_slope);
+  SR_CHECK_LAUNCH("linear_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* dy, int n, int in, int out,
+                                 float act_slope, float* dz, float* dx, float* dw, float* db, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && w && y && dy && dz && n > 0 && in > 0 && out > 0, "sr_linear_bwd_f32: bad argument");
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk((long long)n * out)), dim3(256), 0, stream, dy, y, dz, act_slope,
+                     (long long)n * out);
+  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(nblk(in), n), dim3(256), 0, stream, dz, w, dx, in, out);
+  if (dw) hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(nblk(in), out), dim3(256), 0, stream, dz, x, dw, db, in, out, n);
+  SR_CHECK_LAUNCH("linear_bwd");
+  return SR_OK;
+}
+
+static int flat_reduce(const float* x, const float* t, const float* shift, long long n, int mode, float sign, float scale,
+                       float* out, float* ws, hipStream_t stream) {
+  FlatRedParams p = {};
+  p.x = x;
+  p.t = t;
+  p.shift = shift;
+  p.part = ws;
+  p.n = n;
+  p.mode = mode;
+  p.sign = sign;
+  int blocks = (int)((n + 4095) / 4096);
+  if (blocks > 4 * RED_SPLITS) blocks = 4 * RED_SPLITS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(flat_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(flat_finalize_kernel, dim3(1), dim3(64), 0, stream, ws, blocks, scale, out);
+  SR_CHECK_LAUNCH("flat_reduce");
+  return SR_OK;
+}
+
+extern "C" int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
+  SR_CHECK_ARG(x && out && ws && n > 0 && ws_bytes >= sr_reduce_workspace_bytes(8), "sr_mean_f32: bad argument");
+  return flat_reduce(x, nullptr, nullptr, n, 0, 1.f, 1.f / (float)n, out, (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int sr_l1_loss_fwd_f32(const float* pred, const float* target, int64_t n, float weight, float* loss, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  SR_CHECK_ARG(pred && target && loss && ws && n > 0 && ws_bytes >= sr_reduce_workspace_bytes(8),
+               "sr_l1_loss_fwd_f32: bad argument");
+  return flat_reduce(pred, target, nullptr, n, 1, 1.f, weight / (float)n, loss, (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int sr_l1_loss_bwd_f32(const float* pred, const float* target, int64_t n, float weight, const float* gout,
+                                  float* dpred, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(pred && target && gout && dpred && n > 0, "sr_l1_loss_bwd_f32: bad argument");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, pred, target, gout, weight / (float)n, dpred,
+                     (long long)n);
+  SR_CHECK_LAUNCH("l1_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_bce_logits_fwd_f32(const float* x, const float* shift, int64_t n, int target_is_real, float weight,
+                                     float* loss, float* dsum, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && loss && ws && n > 0 && ws_bytes >= sr_reduce_workspace_bytes(8), "sr_bce_logits_fwd_f32: bad argument");
+  const float sign = target_is_real ? -1.f : 1.f;
+  int rc = flat_reduce(x, nullptr, shift, n, 2, sign, weight / (float)n, loss, (float*)ws, stream);
+  if (rc) return rc;
+  if (dsum) rc = flat_reduce(x, nullptr, shift, n, 3, sign, weight / (float)n, dsum, (float*)ws, stream);
+  return rc;
+}
+
+extern "C" int sr_bce_logits_bwd_f32(const float* x, const float* shift, int64_t n, int target_is_real, float weight,
+                                     const float* gout, float* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && gout && dx && n > 0, "sr_bce_logits_bwd_f32: bad argument");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, shift, gout, target_is_real ? -1.f : 1.f,
+                     weight / (float)n, dx, (long long)n);
+  SR_CHECK_LAUNCH("bce_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_fill_scaled_f32(const float* gout, const float* s, float scale, float* dx, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(gout && s && dx && n > 0, "sr_fill_scaled_f32: bad argument");
+  hipLaunchKernelGGL(fill_scaled_kernel, dim3(nblk(n)), dim3(256), 0, stream, gout, s, scale, dx, (long long)n);
+  SR_CHECK_LAUNCH("fill_scaled");
+  return SR_OK;
+}
+
+extern "C" int sr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "sr_adam_step_f32: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long long)n, lr,
+                     beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  SR_CHECK_LAUNCH("adam");
+  return SR_OK;
+}
+
+extern "C" int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(dst && src && n > 0, "sr_axpby_f32: bad argument");
+  hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, stream, dst, src, a, b, (long long)n);
+  SR_CHECK_LAUNCH("axpby");
+  return SR_OK;
+}

@@ -15,6 +15,20 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+_scratch = {}
+
+
+def scratch(dev, nbytes, tag='ws'):
+    """Grow-only per-device scratch buffer (reduction workspaces, wgrad slabs).  Launches that share it are
+    ordered on the current stream."""
+    key = (str(dev), tag)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    return buf
+
+
 def _need_cuda(t, what):
     if not t.is_cuda:
         raise _lib.SrHipError(f'{what}: tensor is on {t.device}; the HIP path has no CPU fallback')
@@ -160,7 +174,7 @@ def conv3x3_wgrad(src, dy, cout, cin, first_seg=None, seg=0, *, upsample=False, 
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
     db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
     nbytes = lib.sr_conv3x3_wgrad_slab_bytes(src.n, H, W)
-    slab = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    slab = scratch(dev, nbytes, 'slab')
     d = _lib.WgradDesc()
     d.x, d.x_img_stride, d.cin_pad, d.in_h, d.in_w, d.upsample = src.ptr, src.img_stride, cin_pad, src.h, src.w, int(upsample)
     d.dy, d.dy_img_stride = dy.ptr, dy.img_stride
@@ -270,7 +284,7 @@ def conv4x4s2_wgrad(src, dy, cout, cin, *, scale=1.0, want_bias=False):
     dw = torch.zeros((cout, cin, 4, 4), dtype=torch.float32, device=dev)
     db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
     nbytes = lib.sr_conv3x3_wgrad_slab_bytes(src.n, H, W)
-    slab = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    slab = scratch(dev, nbytes, 'slab')
     d = _lib.WgradDesc()
     d.x, d.x_img_stride, d.cin_pad, d.in_h, d.in_w, d.upsample = src.ptr, src.img_stride, cin_pad, src.h, src.w, 0
     d.dy, d.dy_img_stride = dy.ptr, dy.img_stride

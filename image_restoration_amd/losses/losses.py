@@ -1,0 +1,56 @@
+"""Losses of the ESRGAN path as HIP reductions.
+
+``L1Loss`` mirrors basicsr/losses/losses.py:80-106 (+ weighted_loss, loss_util.py:57-95); ``GANLoss`` mirrors
+:359-461 for ``gan_type='vanilla'`` (BCEWithLogitsLoss :379-380).  ``GANLoss.relativistic`` is the fused
+form of ``cri_gan(a - torch.mean(b), target, is_disc)`` used by ESRGANModel (esrgan_model.py:40-41,67,71).
+"""
+import torch
+from torch import nn
+
+from .. import hip_autograd as A
+from ..utils.registry import LOSS_REGISTRY
+
+_reduction_modes = ['none', 'mean', 'sum']
+
+
+@LOSS_REGISTRY.register()
+class L1Loss(nn.Module):
+    """loss_weight * mean(|pred - target|); 'sum' rescales the same reduction; element weights / 'none' are
+    not on the path (the reference's ESRGAN recipes use the default 'mean', train_ESRGAN_x4.yml:84-87)."""
+
+    def __init__(self, loss_weight=1.0, reduction='mean'):
+        super().__init__()
+        if reduction not in _reduction_modes:
+            raise ValueError(f'Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}')
+        self.loss_weight, self.reduction = loss_weight, reduction
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        if weight is not None or self.reduction == 'none':
+            raise NotImplementedError('element-wise weights / reduction="none" are not implemented on the HIP path')
+        assert pred.shape == target.shape
+        scale = self.loss_weight * (pred.numel() if self.reduction == 'sum' else 1.0)
+        return A.L1LossFn.apply(pred, target.detach(), float(scale))
+
+
+@LOSS_REGISTRY.register()
+class GANLoss(nn.Module):
+    """GANLoss('vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight): loss_weight applies to generator
+    calls only (is_disc=False), exactly as losses.py:460-461."""
+
+    def __init__(self, gan_type, real_label_val=1.0, fake_label_val=0.0, loss_weight=1.0):
+        super().__init__()
+        if gan_type != 'vanilla':
+            raise NotImplementedError(f'GAN type {gan_type} is not implemented.')
+        if real_label_val != 1.0 or fake_label_val != 0.0:
+            raise NotImplementedError('only hard labels 1.0 / 0.0 are implemented on the HIP path')
+        self.gan_type, self.loss_weight = gan_type, loss_weight
+        self.real_label_val, self.fake_label_val = real_label_val, fake_label_val
+
+    def forward(self, input, target_is_real, is_disc=False):
+        w = 1.0 if is_disc else self.loss_weight
+        return A.BCELogitsFn.apply(input, None, bool(target_is_real), float(w))
+
+    def relativistic(self, pred, other, target_is_real, is_disc=False):
+        """== self(pred - torch.mean(other), target_is_real, is_disc) in one fused reduction."""
+        w = 1.0 if is_disc else self.loss_weight
+        return A.BCELogitsFn.apply(pred, other, bool(target_is_real), float(w))

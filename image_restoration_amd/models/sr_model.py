@@ -1,0 +1,119 @@
+"""SRModel: generator-only training / testing (PSNR pre-training of RRDBNet).
+
+Counterpart of basicsr/models/sr_model.py:14-133,204-209 on the HIP path: same option keys, same step order
+(zero_grad -> forward -> pixel loss -> backward -> Adam -> EMA), same log keys."""
+from collections import OrderedDict
+
+import torch
+
+from .. import optim
+from ..archs import build_network
+from ..losses import build_loss
+from ..utils.registry import MODEL_REGISTRY
+from .base_model import BaseModel
+
+
+@MODEL_REGISTRY.register()
+class SRModel(BaseModel):
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.net_g = self.model_to_device(build_network(opt['network_g']))
+        self.print_network(self.net_g)
+        load_path = self.opt['path'].get('pretrain_network_g', None)
+        if load_path is not None:
+            self.load_network(self.net_g, load_path, self.opt['path'].get('strict_load_g', True))
+        if self.is_train:
+            self.init_training_settings()
+
+    def _init_ema(self, train_opt):
+        self.ema_decay = train_opt.get('ema_decay', 0)
+        if self.ema_decay > 0:
+            self.logger.info(f'Use Exponential Moving Average with decay: {self.ema_decay}')
+            self.net_g_ema = build_network(self.opt['network_g']).to(self.device)
+            load_path = self.opt['path'].get('pretrain_network_g', None)
+            if load_path is not None:
+                self.load_network(self.net_g_ema, load_path, self.opt['path'].get('strict_load_g', True), 'params_ema')
+            self.net_g_ema.eval()
+            self._ema_pending_copy = load_path is None
+
+    def _finish_ema(self):
+        """After the optimiser built net_g's arena: flatten the EMA copy the same way."""
+        if self.ema_decay > 0:
+            self._ema_flat = optim.flatten_parameters(self.net_g_ema)
+            if self._ema_pending_copy:
+                self.model_ema(0)  # copy net_g weight
+
+    def init_training_settings(self):
+        self.net_g.train()
+        train_opt = self.opt['train']
+        self._init_ema(train_opt)
+        self.cri_pix = build_loss(train_opt['pixel_opt']).to(self.device) if train_opt.get('pixel_opt') else None
+        if train_opt.get('perceptual_opt'):
+            raise NotImplementedError('PerceptualLoss (VGG19 features) is not on the HIP path yet (SURVEY.md §8 f2)')
+        self.cri_perceptual = None
+        if self.cri_pix is None and self.cri_perceptual is None:
+            raise ValueError('Both pixel and perceptual losses are None.')
+        self.setup_optimizers()
+        self.setup_schedulers()
+        self._finish_ema()
+
+    def setup_optimizers(self):
+        train_opt = self.opt['train']
+        optim_params = []
+        for k, v in self.net_g.named_parameters():
+            if v.requires_grad:
+                optim_params.append(v)
+            else:
+                self.logger.warning(f'Params {k} will not be optimized.')
+        optim_type = train_opt['optim_g'].pop('type')
+        self.optimizer_g = self.get_optimizer(optim_type, optim_params, modules=[self.net_g], **train_opt['optim_g'])
+        self.optimizers.append(self.optimizer_g)
+
+    def feed_data(self, data):
+        self.lq = data['lq'].to(self.device)
+        if 'gt' in data:
+            self.gt = data['gt'].to(self.device)
+
+    def _step(self, optimizer):
+        """DP gradient exchange (one arena all-reduce) + fused Adam."""
+        scale = optimizer.all_reduce_grads() if self.opt['dist'] else 1.0
+        optimizer.step(grad_scale=scale)
+
+    def optimize_parameters(self, current_iter):
+        self.optimizer_g.zero_grad()
+        self.output = self.net_g(self.lq)
+        loss_dict = OrderedDict()
+        l_pix = self.cri_pix(self.output, self.gt)
+        loss_dict['l_pix'] = l_pix
+        l_pix.backward()
+        self._step(self.optimizer_g)
+        self.log_dict = self.reduce_loss_dict(loss_dict)
+        if self.ema_decay > 0:
+            self.model_ema(decay=self.ema_decay)
+
+    def test(self):
+        if hasattr(self, 'net_g_ema'):
+            self.net_g_ema.eval()
+            with torch.no_grad():
+                self.output = self.net_g_ema(self.lq)
+        else:
+            self.net_g.eval()
+            with torch.no_grad():
+                self.output = self.net_g(self.lq)
+            self.net_g.train()
+
+    def get_current_visuals(self):
+        out_dict = OrderedDict()
+        out_dict['lq'] = self.lq.detach().cpu()
+        out_dict['result'] = self.output.detach().cpu()
+        if hasattr(self, 'gt'):
+            out_dict['gt'] = self.gt.detach().cpu()
+        return out_dict
+
+    def save(self, epoch, current_iter):
+        if hasattr(self, 'net_g_ema'):
+            self.save_network([self.net_g, self.net_g_ema], 'net_g', current_iter, param_key=['params', 'params_ema'])
+        else:
+            self.save_network(self.net_g, 'net_g', current_iter)
+        self.save_training_state(epoch, current_iter)

@@ -83,3 +83,53 @@ def uniform_input(seed, shape):
 def signed_input(seed, shape, scale=1.0):
     """Zero-mean features for block-level tests."""
     return ((np.random.default_rng(seed).random(shape, dtype=np.float32) * 2 - 1) * np.float32(scale)).astype(np.float32)
+
+
+def vgg128_param_shapes(num_in_ch, num_feat):
+    """(name, shape, kind) in state_dict order of VGGStyleDiscriminator128 (discriminator_arch.py:21-46)."""
+    nf = num_feat
+    out = []
+
+    def conv(name, ci, co, k, bias):
+        out.append((f'{name}.weight', (co, ci, k, k), 'conv'))
+        if bias:
+            out.append((f'{name}.bias', (co,), 'bias'))
+
+    def bn(name, c):
+        out.extend([(f'{name}.weight', (c,), 'bn_w'), (f'{name}.bias', (c,), 'bias'), (f'{name}.running_mean', (c,), 'rm'),
+                    (f'{name}.running_var', (c,), 'rv'), (f'{name}.num_batches_tracked', (), 'nbt')])
+
+    conv('conv0_0', num_in_ch, nf, 3, True)
+    conv('conv0_1', nf, nf, 4, False)
+    bn('bn0_1', nf)
+    for i, (ci, co) in enumerate([(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)], start=1):
+        conv(f'conv{i}_0', ci, co, 3, False)
+        bn(f'bn{i}_0', co)
+        conv(f'conv{i}_1', co, co, 4, False)
+        bn(f'bn{i}_1', co)
+    out.extend([('linear1.weight', (100, nf * 8 * 16), 'lin'), ('linear1.bias', (100,), 'bias'),
+                ('linear2.weight', (1, 100), 'lin'), ('linear2.bias', (1,), 'bias')])
+    return out
+
+
+def vgg128_state_dict(seed, num_in_ch=3, num_feat=64):
+    """Deterministic VGGStyleDiscriminator128 state (non-trivial BN affine and running statistics)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for name, shape, kind in vgg128_param_shapes(num_in_ch, num_feat):
+        if kind == 'conv':
+            fan_in = shape[1] * shape[2] * shape[3]
+            sd[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(math.sqrt(2.0 / fan_in) * 0.7)).astype(np.float32)
+        elif kind == 'lin':
+            sd[name] = ((rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(1.0 / math.sqrt(shape[1]))).astype(np.float32)
+        elif kind == 'bias':
+            sd[name] = ((rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(0.1)).astype(np.float32)
+        elif kind == 'bn_w':
+            sd[name] = (1.0 + (rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(0.2)).astype(np.float32)
+        elif kind == 'rm':
+            sd[name] = ((rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(0.1)).astype(np.float32)
+        elif kind == 'rv':
+            sd[name] = (0.5 + rng.random(shape, dtype=np.float32)).astype(np.float32)
+        else:
+            sd[name] = np.array(0, dtype=np.int64)
+    return sd

@@ -166,6 +166,62 @@ int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream);
  * gradient ((in_h-2)/2+1 rows); upsample/seg unused.  Slab size: sr_conv3x3_wgrad_slab_bytes(n, out_h, out_w). */
 int sr_conv4x4s2_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream);
 
+/* ------------------------------------------------- non-conv training ops ---- */
+/* All reductions are two-stage and deterministic.  `ws` is a scratch buffer of at least
+ * sr_reduce_workspace_bytes(channels) bytes (channels = 8 for the flat reductions). */
+size_t sr_reduce_workspace_bytes(int channels);
+
+/* nn.BatchNorm2d(c, affine) + LeakyReLU(slope) on CB8 (discriminator_arch.py:23-49,57-70):
+ *   train=1: batch statistics (biased var for normalisation), running stats updated with `momentum` and the
+ *            unbiased variance (torch semantics); train=0: running statistics.
+ *   save_mean / save_invstd [c] are written for the backward.  slope = 1 gives plain BatchNorm. */
+int sr_bn_lrelu_fwd_f32(const float* x, int64_t x_img_stride, float* y, int64_t y_img_stride, int n, int c, int h, int w,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, int train,
+                        float momentum, float eps, float slope, float* save_mean, float* save_invstd, void* ws,
+                        size_t ws_bytes, void* stream);
+/* Backward of the above given dL/dy and the saved OUTPUT y (LeakyReLU mask = y > 0): writes dx, dgamma, dbeta. */
+int sr_bn_lrelu_bwd_f32(const float* x, int64_t x_img_stride, const float* dy, int64_t dy_img_stride, const float* y,
+                        int64_t y_img_stride, float* dx, int64_t dx_img_stride, int n, int c, int h, int w,
+                        const float* gamma, const float* save_mean, const float* save_invstd, int train, float slope,
+                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* dz = dy * (y > 0 ? 1 : slope): LeakyReLU backward from the saved OUTPUT (inplace=True semantics of the reference). */
+int sr_lrelu_bwd_f32(const float* dy, const float* y, float* dz, float slope, int64_t n, void* stream);
+
+/* nn.Linear(in, out) + LeakyReLU(act_slope; 1 = none) (discriminator_arch.py:45-46,69-71), row-major x [n][in]. */
+int sr_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int n, int in, int out, float act_slope,
+                      void* stream);
+/* dz [n][out] scratch; dx [n][in], dw [out][in], db [out] may each be NULL. */
+int sr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* dy, int n, int in, int out,
+                      float act_slope, float* dz, float* dx, float* dw, float* db, void* stream);
+
+/* out[0] = mean(x) */
+int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+/* L1Loss(loss_weight, reduction='mean') (losses.py:80-106): loss[0] = weight*mean|pred-target|;
+ * backward: dpred = gout[0]*weight/n*sign(pred-target). */
+int sr_l1_loss_fwd_f32(const float* pred, const float* target, int64_t n, float weight, float* loss, void* ws,
+                       size_t ws_bytes, void* stream);
+int sr_l1_loss_bwd_f32(const float* pred, const float* target, int64_t n, float weight, const float* gout, float* dpred,
+                       void* stream);
+/* GANLoss('vanilla') = BCEWithLogitsLoss (losses.py:379-380,438-461) on z = x - shift[0] (shift = device scalar, the
+ * batch mean of the other logits in the relativistic form, esrgan_model.py:40-41,67,71; NULL = 0):
+ *   loss[0] = weight*mean(softplus(-z)) for target real, weight*mean(softplus(z)) for target fake;
+ *   dsum[0] (optional) = weight*mean(dBCE/dz), the gradient that flows into the subtracted mean.
+ *   backward: dx = gout[0]*weight/n*dBCE/dz. */
+int sr_bce_logits_fwd_f32(const float* x, const float* shift, int64_t n, int target_is_real, float weight, float* loss,
+                          float* dsum, void* ws, size_t ws_bytes, void* stream);
+int sr_bce_logits_bwd_f32(const float* x, const float* shift, int64_t n, int target_is_real, float weight,
+                          const float* gout, float* dx, void* stream);
+/* dx[i] = scale*gout[0]*s[0] for all i (gradient of a subtracted batch mean). */
+int sr_fill_scaled_f32(const float* gout, const float* s, float scale, float* dx, int64_t n, void* stream);
+
+/* torch.optim.Adam step (base_model.py:78-83; lr/betas from the yml) on flat fp32 arenas; step counts from 1;
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int sr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* dst = a*dst + b*src (EMA: base_model.py:50-57 with a = decay, b = 1-decay). */
+int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, void* stream);
+
 /* ------------------------------------------------------- whole generator ---- */
 
 typedef struct sr_rrdbnet_cfg {
@@ -192,7 +248,8 @@ int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const
  *   sr_rrdbnet_forward_train_f32  == RRDBNet.forward under autograd (esrgan_model.py:18)
  *   sr_rrdbnet_backward_f32       == autograd's backward through it (esrgan_model.py:47): given dL/dy it writes
  *       dL/dparam for every parameter (host_dparams: HOST array of DEVICE pointers in state_dict order, each
- *       shaped like its parameter; NULL entries are skipped) and, if dx != NULL, dL/dx.
+ *       shaped like its parameter; NULL entries are skipped; accumulate=1 adds into them, which is how the
+ *       gradient lands directly in a flat all-reduce / optimiser arena) and, if dx != NULL, dL/dx.
  * packed_dgrad holds the transposed/flipped weight images (sr_rrdbnet_pack_dgrad_f32). */
 size_t sr_rrdbnet_saved_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
 size_t sr_rrdbnet_backward_workspace_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
@@ -203,7 +260,7 @@ int sr_rrdbnet_forward_train_f32(const sr_rrdbnet_cfg* cfg, const float* packed,
                                  int w, void* saved, size_t saved_bytes, void* stream);
 int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad, const void* saved, size_t saved_bytes,
                             const float* dy, int n, int h, int w, float* const* host_dparams, float* dx,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 
 /* ------------------------------------------------------------ measurement ---- */
 

@@ -71,3 +71,30 @@ def test_scale_2_and_1(golden):
         u = 2 if scale == 2 else 4
         pu = R.pixel_unshuffle(torch.arange(2 * 3 * 8 * 8, dtype=torch.float32).view(2, 3, 8, 8), u)
         assert np.array_equal(pu.numpy(), g[f'unshuffle_s{scale}'])
+
+
+def test_vgg_discriminator_oracle(golden):
+    from oracle import discriminator_ref as D
+    g = golden('g_g_vgg128')
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in synth.vgg128_state_dict(61, 3, 8).items()}
+    for k in sd:
+        if sd[k].is_floating_point() and 'running' not in k:
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    out = D.vgg128_forward(x, sd, train=True)
+    _close(out, g['out_train'], 1e-5)
+    (out * torch.from_numpy(g['R'])).sum().backward()
+    _close(x.grad, g['grad_x'], 1e-6)
+    _close(sd['conv2_1.weight'].grad, g['grad_conv2_1_weight'], 1e-5)
+    _close(sd['bn3_0.running_var'], g['buf_bn3_0_running_var'], 1e-6)
+    with torch.no_grad():
+        _close(D.vgg128_forward(x.detach(), sd, train=False), g['out_eval'], 1e-5)
+
+
+def test_loss_oracle(golden):
+    from oracle import discriminator_ref as D
+    g = golden('g_h_losses')
+    _close(D.l1_loss(torch.from_numpy(g['l1_pred']), torch.from_numpy(g['l1_target']), 1e-2), g['l1_loss'], 1e-8)
+    a, b = torch.from_numpy(g['gan_map_a']), torch.from_numpy(g['gan_map_b'])
+    _close(D.gan_loss(a - b.mean(), True, False, 5e-3), g['gan_map_real1_disc0_rel1_loss'], 1e-8)
+    _close(D.gan_loss(a, False, True, 5e-3), g['gan_map_real0_disc1_rel0_loss'], 1e-7)
