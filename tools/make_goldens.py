@@ -294,7 +294,39 @@ def g_j(ref):
     save('g_j_lr', **arrays)
 
 
-ALL = {'g_g': g_g, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+def g_k(ref):
+    """G-k: tiled inference of a 40x56 frame, tile 16, pad 4 (the build's paste rule, image_restoration_amd/tiling.py)
+    with the REFERENCE RRDBNet.forward applied to every padded cell."""
+    from image_restoration_amd.tiling import plan_tiles
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=32, num_block=2, num_grow_ch=16)
+    net = ref.RRDBNet(**cfg).eval()
+    net.load_state_dict(to_torch(synth.rrdbnet_state_dict(91, **cfg)), strict=True)
+    img = torch.from_numpy(synth.uniform_input(92, (1, 3, 40, 56)))
+    out = torch.zeros((1, 3, 160, 224))
+    with torch.no_grad():
+        for (y0, y1, x0, x1), (py0, py1, px0, px1) in plan_tiles(40, 56, 16, 4):
+            sr = net(img[:, :, py0:py1, px0:px1])
+            oy, ox = (y0 - py0) * 4, (x0 - px0) * 4
+            out[:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4] = sr[:, :, oy:oy + (y1 - y0) * 4, ox:ox + (x1 - x0) * 4]
+    save('g_k_tiled', img=img.numpy(), out=out.numpy())
+
+
+def g_m(ref):
+    """G-m: EnlargedSampler index streams (data_sampler.py:29-42) for 2 ranks, 3 epochs."""
+    class DS:
+        def __len__(self):
+            return 10
+    arrays = {}
+    for rank in (0, 1):
+        s = ref.data_sampler.EnlargedSampler(DS(), 2, rank, ratio=3)
+        for epoch in (0, 1, 5):
+            s.set_epoch(epoch)
+            arrays[f'r{rank}_e{epoch}'] = np.array(list(iter(s)), dtype=np.int64)
+        arrays[f'r{rank}_len'] = np.array(len(s))
+    save('g_m_sampler', **arrays)
+
+
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():
