@@ -115,6 +115,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -132,6 +133,9 @@ def main():
 
     import image_restoration_amd as ira
     from image_restoration_amd.utils import synth
+    if args.groups:
+        from image_restoration_amd import _lib
+        _lib.check(_lib.load().sr_set_forward_groups(args.groups), 'sr_set_forward_groups')
     net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
     x = torch.from_numpy(synth.uniform_input(1234 + rank, (BATCH, 3, TILE, TILE))).to(dev)

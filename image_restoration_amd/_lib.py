@@ -102,6 +102,7 @@ SIGNATURES = {
     'sr_rrdbnet_pack_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     'sr_rrdbnet_forward_f32': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_set_forward_groups': (C.c_int, [C.c_int]),
     'sr_rrdbnet_saved_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_backward_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_packed_dgrad_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),

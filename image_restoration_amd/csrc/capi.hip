@@ -91,3 +91,16 @@ extern "C" int sr_profile_stop(sr_launch_record* out, int capacity, int* count) 
   g_prof.ev.clear();
   return rc;
 }
+
+// ---- tuning knob: number of concurrent image groups of the whole-network forward ----
+namespace {
+int g_forward_groups = 1;
+}
+namespace sr {
+int forward_groups() { return g_forward_groups; }
+}  // namespace sr
+extern "C" int sr_set_forward_groups(int groups) {
+  SR_CHECK_ARG(groups >= 1 && groups <= 4, "sr_set_forward_groups: 1..4");
+  g_forward_groups = groups;
+  return SR_OK;
+}

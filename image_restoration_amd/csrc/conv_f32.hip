@@ -62,7 +62,9 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int COT, int PT, int KS, bool NCHW_OUT>
+// ABL: timing-only ablation bits for tools/conv_ablate.hip (never instantiated non-zero in the library):
+//   1 = no LDS-DMA refill in the loop, 2 = no per-chunk barrier, 8 = no output store
+template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TH = 4 * PT, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
@@ -167,9 +169,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
   stage(0, 0);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    if constexpr (!(ABL & 1)) {
+      if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    }
     compute(c & 1);
-    __syncthreads();  // drains the LDS-DMA of chunk c+1 and frees buffer c&1
+    if constexpr (!(ABL & 2)) __syncthreads();  // drains the LDS-DMA of chunk c+1 and frees buffer c&1
   }
 
   // ---- epilogue: [old +] bias, LeakyReLU, residual scale-adds, optional accumulate / LReLU-backward mask
@@ -219,7 +223,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * p.mask_slope;
           }
-          *(f32x4*)o = v;
+          if constexpr (ABL & 8) {
+            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));  // timing-only: keep the value, skip the store
+          } else {
+            *(f32x4*)o = v;
+          }
         }
       }
     }
@@ -248,7 +256,7 @@ int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
+    r.kernel_id = PT == 4 ? 13 : (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
@@ -355,6 +363,13 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   if (rc) return rc;
   if (d->out_nchw) return launch<1, PT, 3, true>(p, d->n, groups, stream, d);
   if (gc == 64) return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
+  // 32-cout groups: 16-row tiles (PT = 4) halve the weight refill per MFMA (measured +2.5..7 % on the RDB conv1-4
+  // shapes, tools/conv_ablate.hip) as long as the launch still has >= 2 workgroups per CU and rows are not wasted.
+  const long long wg4 = (long long)p.tiles_x * sr::cdiv(p.H, 16) * d->n * groups;
+  if (p.H % 16 == 0 && wg4 >= 512) {
+    p.tiles_y = sr::cdiv(p.H, 16);
+    return launch<1, 4, 3, false>(p, d->n, groups, stream, d);
+  }
   return launch<1, PT, 3, false>(p, d->n, groups, stream, d);
 }
 
@@ -452,5 +467,6 @@ extern "C" const char* sr_kernel_name(int id) {
                                   "wgrad3x3_f32_kernelILi1ELi4ELi1E", "wgrad3x3_f32_kernelILi2ELi2ELi1E",
                                   "wgrad3x3_f32_kernelILi2ELi1ELi1E"};
   if (id >= 8 && id < 13) return wnames[id - 8];
+  if (id == 13) return "conv_f32_kernelILi1ELi4ELi3ELb0E";
   return (id >= 0 && id < 8) ? names[id] : "";
 }

@@ -12,6 +12,7 @@ void set_error(const char* fmt, ...);
 bool prof_on();
 void prof_begin(hipStream_t s, const sr_launch_record& r);
 void prof_end(hipStream_t s);
+int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
 
 #define SR_CHECK_ARG(cond, ...)            \
   do {                                     \

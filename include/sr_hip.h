@@ -243,6 +243,12 @@ int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_para
 int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h,
                            int w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Tuning knob (process-wide): with groups > 1 the forward cuts the batch into `groups` image groups (1..4) that run
+ * the same launch sequence concurrently on internal side streams forked from / joined to `stream` with events
+ * (graph-capturable).  Default 1: measured on MI355X the overlap buys < 0.5 % (the per-launch cost is LDS-DMA
+ * refill traffic and the output-store drain, not idle CUs), so by default every launch goes to `stream` itself. */
+int sr_set_forward_groups(int groups);
+
 /* Training: forward that KEEPS every activation the backward needs (one concat buffer per dense block,
  * 3*num_block+1 of them, plus the head maps) in `saved`, and the matching backward.
  *   sr_rrdbnet_forward_train_f32  == RRDBNet.forward under autograd (esrgan_model.py:18)
