@@ -1,0 +1,90 @@
+"""U-Net discriminator with spectral normalisation on the HIP path.
+
+BASELINE.json names ``UNetDiscriminatorSN`` for the 128->512 training configs, but the mounted reference does not
+contain it (this fork predates it; ``grep -ri UNetDiscriminator /root/reference`` has no hits).
+It is built here from the published architecture (Real-ESRGAN, arXiv:2107.10833 §3.3):
+conv0 3x3(+bias)+LReLU -> 3x [SN conv4x4/s2, no bias, LReLU] -> 3x [bilinear x2 (align_corners=False) -> SN conv3x3,
+no bias, LReLU, + skip from the matching encoder level] -> 2x SN conv3x3 + LReLU -> conv3x3 -> 1 logit map.
+**Parity unpinned by the reference**: the oracle (oracle/unet_discriminator_ref.py) is a restatement of the same
+published architecture with torch.nn.utils.spectral_norm; tests compare against that.
+
+state_dict keys follow torch.nn.utils.spectral_norm: ``convK.weight_orig`` (parameter), ``convK.weight_u`` /
+``convK.weight_v`` (buffers); conv0 / conv9 have ``weight`` and ``bias``.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import _lib
+from .. import hip_autograd as A
+from ..utils.registry import ARCH_REGISTRY
+from .arch_util import Conv3x3Params
+
+
+class SNConvParams(nn.Module):
+    """weight_orig [cout, cin, k, k] + power-iteration buffers weight_u [cout], weight_v [cin*k*k]."""
+
+    def __init__(self, cin, cout, ksize, eps=1e-12):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.eps = cin, cout, ksize, eps
+        w = torch.empty(cout, cin, ksize, ksize)
+        init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight_orig = nn.Parameter(w)
+        # torch.nn.utils.spectral_norm initialises u, v as normalised gaussians
+        self.register_buffer('weight_u', nn.functional.normalize(torch.randn(cout), dim=0, eps=eps))
+        self.register_buffer('weight_v', nn.functional.normalize(torch.randn(cin * ksize * ksize), dim=0, eps=eps))
+
+    def weight(self):
+        return A.SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
+
+    def extra_repr(self):
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, spectral_norm [HIP]'
+
+
+@ARCH_REGISTRY.register()
+class UNetDiscriminatorSN(nn.Module):
+    """UNetDiscriminatorSN(num_in_ch, num_feat=64, skip_connection=True): [N, C, H, W] -> [N, 1, H, W] logits
+    (H, W multiples of 8)."""
+
+    def __init__(self, num_in_ch, num_feat=64, skip_connection=True):
+        super().__init__()
+        nf = num_feat
+        self.num_in_ch, self.num_feat, self.skip_connection = num_in_ch, nf, skip_connection
+        self.conv0 = Conv3x3Params(num_in_ch, nf, bias=True)
+        self.conv1 = SNConvParams(nf, nf * 2, 4)
+        self.conv2 = SNConvParams(nf * 2, nf * 4, 4)
+        self.conv3 = SNConvParams(nf * 4, nf * 8, 4)
+        self.conv4 = SNConvParams(nf * 8, nf * 4, 3)
+        self.conv5 = SNConvParams(nf * 4, nf * 2, 3)
+        self.conv6 = SNConvParams(nf * 2, nf, 3)
+        self.conv7 = SNConvParams(nf, nf, 3)
+        self.conv8 = SNConvParams(nf, nf, 3)
+        self.conv9 = Conv3x3Params(nf, 1, bias=True)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.SrHipError('UNetDiscriminatorSN.forward runs only on a HIP device (no CPU fallback)')
+        assert x.size(2) % 8 == 0 and x.size(3) % 8 == 0, f'input {tuple(x.shape)} must be a multiple of 8 in H and W'
+        conv = A.ConvFn.apply
+        x0 = conv(A.ToCB8.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
+        x1 = conv(x0, self.conv1.weight(), None, 0.2)
+        x2 = conv(x1, self.conv2.weight(), None, 0.2)
+        x3 = conv(x2, self.conv3.weight(), None, 0.2)
+        x3 = A.Bilinear2xFn.apply(x3)
+        x4 = conv(x3, self.conv4.weight(), None, 0.2)
+        if self.skip_connection:
+            x4 = A.AddFn.apply(x4, x2)
+        x4 = A.Bilinear2xFn.apply(x4)
+        x5 = conv(x4, self.conv5.weight(), None, 0.2)
+        if self.skip_connection:
+            x5 = A.AddFn.apply(x5, x1)
+        x5 = A.Bilinear2xFn.apply(x5)
+        x6 = conv(x5, self.conv6.weight(), None, 0.2)
+        if self.skip_connection:
+            x6 = A.AddFn.apply(x6, x0)
+        out = conv(x6, self.conv7.weight(), None, 0.2)
+        out = conv(out, self.conv8.weight(), None, 0.2)
+        out = conv(out, self.conv9.weight, self.conv9.bias, 1.0)
+        return A.FromCB8.apply(out, 1)

@@ -234,6 +234,7 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __re
 // ------------------------------------------------------------------ flat reductions / losses
 // mode 0: sum x ; 1: sum |x - t| (L1) ; 2: sum softplus(sign*(x - shift)) (BCE-with-logits vs target 1: sign=-1, 0: +1)
 // mode 3: sum sigmoid-based derivative d/dx of mode 2 (for the gradient through the mean of the other logits)
+// mode 4: sum x*t (dot product)
 __device__ __forceinline__ float softplus(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void flat_reduce_kernel(const FlatRedParams p)
     if (p.mode == 0) s += v;
     else if (p.mode == 1) s += fabsf(v - p.t[i]);
     else if (p.mode == 2) s += softplus(p.sign * (v - shift));
+    else if (p.mode == 4) s += v * p.t[i];
     else s += p.sign * sigmoidf(p.sign * (v - shift));
   }
   s = block_sum(s, sh);
@@ -312,6 +314,143 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 __global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = a * dst[i] + b * src[i];
+}
+
+// ------------------------------------------------------------------ bilinear x2 (align_corners=False) on CB8
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False): source coordinate (o+0.5)/2-0.5 clamped at 0,
+// second tap clamped at size-1.  Both directions are written as gathers (deterministic).
+__device__ __forceinline__ void bil_taps(int o, int size, int& i0, int& i1, float& w0, float& w1) {
+  float s = (o + 0.5f) * 0.5f - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < size - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+  w0 = 1.f - w1;
+}
+__global__ void bilinear2x_fwd_kernel(const float* __restrict__ src, long long src_ns, float* __restrict__ dst,
+                                      long long dst_ns, int cblocks, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int W2 = 2 * w, H2 = 2 * h;
+  const int ox = (int)(r % W2);
+  r /= W2;
+  const int oy = (int)(r % H2);
+  r /= H2;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bil_taps(oy, h, y0, y1, wy0, wy1);
+  bil_taps(ox, w, x0, x1, wx0, wx1);
+  const float* b = src + n * src_ns + (long long)cb * h * w * 8 + half * 4;
+  const float4 a00 = *(const float4*)(b + ((long long)y0 * w + x0) * 8), a01 = *(const float4*)(b + ((long long)y0 * w + x1) * 8),
+               a10 = *(const float4*)(b + ((long long)y1 * w + x0) * 8), a11 = *(const float4*)(b + ((long long)y1 * w + x1) * 8);
+  float4 o;
+  o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+  o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+  o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+  o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+  *(float4*)(dst + n * dst_ns + (((long long)cb * H2 + oy) * W2 + ox) * 8 + half * 4) = o;
+}
+// gsrc[y][x] = sum over the (at most 4x4) outputs whose taps touch (y, x)
+__global__ void bilinear2x_bwd_kernel(const float* __restrict__ g, long long g_ns, float* __restrict__ gsrc,
+                                      long long gsrc_ns, int cblocks, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int x = (int)(r % w);
+  r /= w;
+  const int y = (int)(r % h);
+  r /= h;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const int W2 = 2 * w, H2 = 2 * h;
+  const float* b = g + n * g_ns + (long long)cb * H2 * W2 * 8 + half * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int oy = 2 * y - 1; oy <= 2 * y + 2; ++oy) {
+    if (oy < 0 || oy >= H2) continue;
+    int y0, y1;
+    float wy0, wy1;
+    bil_taps(oy, h, y0, y1, wy0, wy1);
+    const float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = 2 * x - 1; ox <= 2 * x + 2; ++ox) {
+      if (ox < 0 || ox >= W2) continue;
+      int x0, x1;
+      float wx0, wx1;
+      bil_taps(ox, w, x0, x1, wx0, wx1);
+      const float wgt = wy * ((x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f));
+      if (wgt == 0.f) continue;
+      const float4 v = *(const float4*)(b + ((long long)oy * W2 + ox) * 8);
+      acc.x += wgt * v.x;
+      acc.y += wgt * v.y;
+      acc.z += wgt * v.z;
+      acc.w += wgt * v.w;
+    }
+  }
+  *(float4*)(gsrc + n * gsrc_ns + (((long long)cb * h + y) * w + x) * 8 + half * 4) = acc;
+}
+
+// ------------------------------------------------------------------ spectral norm (torch.nn.utils.spectral_norm)
+// W viewed as [rows][cols] row-major.  t = W^T u : one thread per column.
+__global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int rows,
+                               int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += W[(long long)r * cols + c] * u[r];
+  t[c] = s;
+}
+// s = W v : one block per row
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                     float* __restrict__ s, int cols) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float a = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) a += W[(long long)r * cols + c] * v[c];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) s[r] = a;
+}
+// single block: out = x / max(||x||, eps); if sigma: sigma[0] = out . x
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
+                                                           float eps, float* sigma) {
+  __shared__ float sh[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i] * x[i];
+  a = block_sum(a, sh);
+  const float nrm = fmaxf(sqrtf(a), eps);
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = x[i] / nrm;
+  if (sigma && threadIdx.x == 0) sigma[0] = a / nrm;
+}
+// single block: sigma = u . s   (eval mode: stored u, fresh s = W v)
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                     float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += a[i] * b[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ sigma, float* __restrict__ out,
+                                long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = W[i] / sigma[0];
+}
+// dW_orig = (G - dot * u[r] v[c]) / sigma
+__global__ void sn_bwd_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
+                              const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ out,
+                              int cols, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (G[i] - dot[0] * u[i / cols] * v[i % cols]) / sigma[0];
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+    ((float4*)out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
 }
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
@@ -515,5 +654,74 @@ extern "C" int sr_axpby_f32(float* dst, const float* src, float a, float b, int6
   SR_CHECK_ARG(dst && src && n > 0, "sr_axpby_f32: bad argument");
   hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, stream, dst, src, a, b, (long long)n);
   SR_CHECK_LAUNCH("axpby");
+  return SR_OK;
+}
+
+
+extern "C" int sr_bilinear2x_fwd_f32(const float* src, int64_t src_ns, float* dst, int64_t dst_ns, int n, int cblocks, int h,
+                                     int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(src && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_fwd_f32: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 8;
+  hipLaunchKernelGGL(bilinear2x_fwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, src, (long long)src_ns, dst,
+                     (long long)dst_ns, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("bilinear2x_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_bilinear2x_bwd_f32(const float* g, int64_t g_ns, float* gsrc, int64_t gsrc_ns, int n, int cblocks, int h,
+                                     int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g && gsrc && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_bwd_f32: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 2;
+  hipLaunchKernelGGL(bilinear2x_bwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, g, (long long)g_ns, gsrc,
+                     (long long)gsrc_ns, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("bilinear2x_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v, int rows, int cols, int update, float eps,
+                                        float* w_sn, float* sigma, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(w_orig && u && v && w_sn && sigma && ws && rows > 0 && cols > 0, "sr_spectral_norm_fwd_f32: bad argument");
+  SR_CHECK_ARG(ws_bytes >= (size_t)(rows + cols) * sizeof(float), "sr_spectral_norm_fwd_f32: workspace too small");
+  float* t = (float*)ws;      // [cols]
+  float* s = t + cols;        // [rows]
+  if (update) {  // one power iteration: v = normalize(W^T u); u = normalize(W v)  (in place, like the reference module)
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(nblk(cols)), dim3(256), 0, stream, w_orig, u, t, rows, cols);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, t, v, cols, eps, (float*)nullptr);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, s, cols);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, s, u, rows, eps, sigma);  // sigma = u.(Wv)
+  } else {
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, s, cols);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, stream, u, s, rows, sigma);
+  }
+  const long long n = (long long)rows * cols;
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(nblk(n)), dim3(256), 0, stream, w_orig, sigma, w_sn, n);
+  SR_CHECK_LAUNCH("spectral_norm_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float* u, const float* v,
+                                        const float* sigma, int rows, int cols, float* g_worig, void* ws, size_t ws_bytes,
+                                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g_wsn && w_sn && u && v && sigma && g_worig && ws && rows > 0 && cols > 0,
+               "sr_spectral_norm_bwd_f32: bad argument");
+  SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(8) + 64, "sr_spectral_norm_bwd_f32: workspace too small");
+  const long long n = (long long)rows * cols;
+  float* dot = (float*)ws;
+  int rc = flat_reduce(g_wsn, w_sn, nullptr, n, 4, 1.f, 1.f, dot, dot + 16, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, g_wsn, u, v, sigma, dot, g_worig, cols, n);
+  SR_CHECK_LAUNCH("spectral_norm_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "sr_add_f32: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 4)), dim3(256), 0, stream, a, b, out, (long long)(n / 4));
+  SR_CHECK_LAUNCH("add");
   return SR_OK;
 }

@@ -284,3 +284,86 @@ def mean(x):
     with torch.cuda.device(dev):
         _lib.check(lib.sr_mean_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), wsb, _stream(dev)), 'sr_mean_f32')
     return out
+
+
+class Bilinear2xFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB8 (sr_bilinear2x_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        n, cb, h, w, _ = x.shape
+        y = torch.empty((n, cb, 2 * h, 2 * w, 8), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_bilinear2x_fwd_f32(x.data_ptr(), cb * h * w * 8, y.data_ptr(), cb * h * w * 32, n, cb, h, w,
+                                                 _stream(x.device)), 'sr_bilinear2x_fwd_f32')
+        ctx.shape = (n, cb, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        n, cb, h, w = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((n, cb, h, w, 8), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.sr_bilinear2x_bwd_f32(g.data_ptr(), cb * h * w * 32, gx.data_ptr(), cb * h * w * 8, n, cb, h, w,
+                                                 _stream(g.device)), 'sr_bilinear2x_bwd_f32')
+        return gx
+
+
+class AddFn(torch.autograd.Function):
+    """a + b of two CB8 activations (sr_add_f32); both inputs receive the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.sr_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a.device)), 'sr_add_f32')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class SpectralNormFn(torch.autograd.Function):
+    """weight = weight_orig / sigma with one power iteration on (u, v) in train mode
+    (sr_spectral_norm_{fwd,bwd}_f32); u and v are buffers updated in place, as torch.nn.utils.spectral_norm does."""
+
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, update, eps):
+        lib = _lib.load()
+        w = weight_orig.contiguous()
+        rows = w.size(0)
+        cols = w.numel() // rows
+        dev = w.device
+        w_sn = torch.empty_like(w)
+        sigma = torch.empty((), dtype=torch.float32, device=dev)
+        wsb = max((rows + cols) * 4, lib.sr_reduce_workspace_bytes(8) + 64)
+        ws = scratch(dev, wsb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_spectral_norm_fwd_f32(w.data_ptr(), u.data_ptr(), v.data_ptr(), rows, cols, int(update), eps,
+                                                    w_sn.data_ptr(), sigma.data_ptr(), ws.data_ptr(), wsb, _stream(dev)),
+                       'sr_spectral_norm_fwd_f32')
+        ctx.save_for_backward(w_sn, u.clone(), v.clone(), sigma)
+        ctx.dims = (rows, cols)
+        return w_sn
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        w_sn, u, v, sigma = ctx.saved_tensors
+        rows, cols = ctx.dims
+        dev = g.device
+        g = g.contiguous()
+        gw = torch.empty_like(g)
+        wsb = max((rows + cols) * 4, lib.sr_reduce_workspace_bytes(8) + 64)
+        ws = scratch(dev, wsb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_spectral_norm_bwd_f32(g.data_ptr(), w_sn.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
+                                                    rows, cols, gw.data_ptr(), ws.data_ptr(), wsb, _stream(dev)),
+                       'sr_spectral_norm_bwd_f32')
+        return gw, None, None, None, None

@@ -195,6 +195,25 @@ int sr_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, 
 int sr_linear_bwd_f32(const float* x, const float* w, const float* y, const float* dy, int n, int in, int out,
                       float act_slope, float* dz, float* dx, float* dw, float* db, void* stream);
 
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB8 and its backward (UNetDiscriminatorSN).
+ * fwd: src [.., h, w] -> dst [.., 2h, 2w]; bwd: g [.., 2h, 2w] -> gsrc [.., h, w]. */
+int sr_bilinear2x_fwd_f32(const float* src, int64_t src_img_stride, float* dst, int64_t dst_img_stride, int n, int cblocks,
+                          int h, int w, void* stream);
+int sr_bilinear2x_bwd_f32(const float* g, int64_t g_img_stride, float* gsrc, int64_t gsrc_img_stride, int n, int cblocks,
+                          int h, int w, void* stream);
+
+/* torch.nn.utils.spectral_norm (dim 0, one power iteration, eps 1e-12) on a weight viewed as [rows][cols]:
+ *   update=1 (train): v = normalize(W^T u), u = normalize(W v) in place; sigma = u.(W v); w_sn = W / sigma.
+ *   update=0 (eval) : stored u, v.     ws >= (rows+cols)*4 bytes.
+ * backward (u, v constants): g_worig = (g_wsn - sum(g_wsn*w_sn) * u v^T) / sigma. */
+int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v, int rows, int cols, int update, float eps,
+                             float* w_sn, float* sigma, void* ws, size_t ws_bytes, void* stream);
+int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float* u, const float* v, const float* sigma,
+                             int rows, int cols, float* g_worig, void* ws, size_t ws_bytes, void* stream);
+
+/* out = a + b (skip connections of UNetDiscriminatorSN); n multiple of 4. */
+int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 /* out[0] = mean(x) */
 int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 /* L1Loss(loss_weight, reduction='mean') (losses.py:80-106): loss[0] = weight*mean|pred-target|;
