@@ -64,14 +64,15 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
 
 // ABL: timing-only ablation bits for tools/conv_ablate.hip (never instantiated non-zero in the library):
 //   1 = no LDS-DMA refill in the loop, 2 = no per-chunk barrier, 8 = no output store
-template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
+// NW = waves per workgroup (4 or 8): 8 waves share one staged weight chunk over twice the rows.
+template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TH = 4 * PT, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
+  constexpr int TH = NW * PT, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
   constexpr int NXU = XBYTES / 1024, NWU = KS * KS * COT;
   constexpr int WBYTES = NWU * 1024, STAGE = XBYTES + WBYTES;
-  constexpr int NXR = (NXU + 3) / 4, NWR = (NWU + 3) / 4;
+  constexpr int NXR = (NXU + NW - 1) / NW, NWR = (NWU + NW - 1) / NW;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
   int xoff[NXR];
 #pragma unroll
   for (int r = 0; r < NXR; ++r) {
-    const int u = r * 4 + wave;
+    const int u = r * NW + wave;
     const int q = u * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
     const float* plane = in_n + (size_t)cb * HWin * 8;
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
-      const int u = r * 4 + wave;
+      const int u = r * NW + wave;
       if (u < NXU) {
         const float* src = xoff[r] >= 0 ? plane + xoff[r] : g_zero_line;
         glds16(src, xs + u * 1024);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
     const float* wsrc = wg + (size_t)cb * (WBYTES / 4) + lane * 4;
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
-      const int u = r * 4 + wave;
+      const int u = r * NW + wave;
       if (u < NWU) glds16(wsrc + u * 256, ws + u * 1024);
     }
   };
@@ -234,9 +235,125 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvParams p) {
   }
 }
 
-template <int COT, int PT, int KS>
+// ---------------------------------------------------------------------------------------------------------
+// Few-output-channel 3x3 conv (conv_last: 64 -> 3, rrdbnet_arch.py:118) on v_mfma_f32_4x4x1_16b_f32.
+// The 32x32 tile would pad 3 couts to 32 (10x wasted MFMA work, 1.08 ms of a 73 ms step); the 16-block 4x4x1 form
+// pads to 4: block b = lane/4 computes D[4 couts][4 pixels] += A[4 couts][1] * B[1][4 pixels], so lane l IS pixel l
+// of a 64-pixel group and holds its 4 couts in 4 registers.  A = W[cout l%4][k] (broadcast within a block column),
+// B = X[k][pixel l].  With K = 9*Cin steps of 8 cycles the layer is HBM-bound (67 MB read per image).
+// Workgroup = 4 waves, tile 16 rows x 32 columns; wave w owns rows 4w..4w+3 as two 64-pixel groups that share the
+// weight fragments.  X tile staged exactly like the main kernel; the weight chunk [9 taps][4 couts][8 ch] is
+// gathered by LDS-DMA out of the standard packed image (first 4 couts of every tap).
+template <int KS>
+__global__ __launch_bounds__(256) void conv_fewcout_f32_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TH = 16, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
+  constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
+  constexpr int NXU = XBYTES / 1024, NT = KS * KS;
+  constexpr int WBYTES = ((NT * 4 * 32 + 1023) / 1024) * 1024, NWU = WBYTES / 1024, STAGE = XBYTES + WBYTES;
+  constexpr int NXR = (NXU + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH;
+  const int HWin = p.in_h * p.in_w;
+  const float* in_n = p.in + (long long)n * p.in_ns;
+
+  int xoff[NXR];
+#pragma unroll
+  for (int r = 0; r < NXR; ++r) {
+    const int u = r * 4 + wave;
+    const int q = u * 64 + lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    const int gy = y0 + p.tap_oy + row, gx = x0 + p.tap_ox + col;
+    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.vH && gx >= 0 && gx < p.vW;
+    const int sy = ((gy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
+    xoff[r] = valid ? ((sy * p.in_w + sx) * 8 + half * 4) : -1;
+  }
+  // weight piece q of the chunk: tap = q/8, cout = (q%8)/2, half = q%2  ->  packed image [tap][32 couts][8]
+  const int wq = wave * 64 + lane;
+  const int woff = (wq < NT * 8) ? ((wq >> 3) * 32 + ((wq & 7) >> 1)) * 8 + (wq & 1) * 4 : -1;
+
+  auto stage = [&](int buf, int cb) {
+    char* xs = smem + buf * STAGE;
+    const float* plane = in_n + (size_t)cb * HWin * 8;
+#pragma unroll
+    for (int r = 0; r < NXR; ++r) {
+      const int u = r * 4 + wave;
+      if (u < NXU) glds16(xoff[r] >= 0 ? plane + xoff[r] : g_zero_line, xs + u * 1024);
+    }
+    if (wave < NWU) {
+      const float* wchunk = p.w + (size_t)cb * (NT * 32 * 8);
+      glds16(woff >= 0 ? wchunk + woff : g_zero_line, xs + XBYTES + wave * 1024);
+    }
+  };
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int prow = lane >> 5, pcol = lane & 31;
+  const int xlane = ((wave * 4 + prow) * XROW + pcol) * 32;  // this lane's pixel, group 0, tap (0,0)
+  const int wlane = (lane & 3) * 32;                         // this lane's cout row of the weight chunk
+
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * STAGE + xlane;
+    const char* ws = smem + buf * STAGE + XBYTES + wlane;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const int tap = dy * KS + dx;
+        const f32x4 w0 = *(const f32x4*)(ws + tap * 128), w1 = *(const f32x4*)(ws + tap * 128 + 16);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const char* xp = xs + ((2 * g + dy) * XROW + dx) * 32;
+          const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[e], a0[e], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[e], a1[e], acc[g], 0, 0, 0);
+        }
+      }
+  };
+
+  const int nchunk = p.cin_blocks;
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    compute(c & 1);
+    __syncthreads();
+  }
+  // epilogue: bias, LeakyReLU, scale; NCHW store (lane = pixel: 32 consecutive x per row and channel)
+  const long long HW = (long long)p.oH * p.oW;
+  const int x = x0 + pcol;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int y = y0 + wave * 4 + 2 * g + prow;
+    if (y >= p.H || x >= p.W) continue;
+    float* o = p.out + (long long)n * p.out_ns + (long long)y * p.oW + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e >= p.cout) break;
+      float v = acc[g][e] + (p.bias ? p.bias[e] : 0.f);
+      v = v > 0.f ? v : v * p.slope;
+      o[e * HW] = v * p.alpha;
+    }
+  }
+}
+
+template <int COT, int PT, int KS, int NW = 4>
 constexpr int conv_lds_bytes() {
-  return 2 * ((((4 * PT + KS - 1) * (32 + KS - 1) * 32 + 1023) / 1024) * 1024 + KS * KS * COT * 1024);
+  return 2 * ((((NW * PT + KS - 1) * (32 + KS - 1) * 32 + 1023) / 1024) * 1024 + KS * KS * COT * 1024);
 }
 
 template <int COT, int PT, int KS, bool NCHW_OUT>
@@ -361,6 +478,39 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   p.tiles_y = sr::cdiv(p.H, 4 * PT);
   rc = check_sizes(p, d->n, "sr_conv3x3_f32");
   if (rc) return rc;
+  if (d->out_nchw && !d->res1 && !d->res2) {
+    // few couts, plain NCHW output: the 4x4x1 kernel (16-row tiles)
+    constexpr int XB = (((16 + 2) * 34 * 32 + 1023) / 1024) * 1024, WB = ((9 * 4 * 32 + 1023) / 1024) * 1024;
+    constexpr int lds = 2 * (XB + WB);
+    static bool attr_set = false;
+    auto kern = conv_fewcout_f32_kernel<3>;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        sr::set_error("sr_conv3x3_f32: hipFuncSetAttribute(%d) failed", lds);
+        return SR_ELAUNCH;
+      }
+      attr_set = true;
+    }
+    p.tiles_y = sr::cdiv(p.H, 16);
+    const bool prof = sr::prof_on();
+    if (prof) {
+      sr_launch_record r = {};
+      r.kernel_id = 14;
+      r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
+      r.cout = d->cout;
+      r.n = d->n;
+      r.h = p.H;
+      r.w = p.W;
+      const double px = (double)d->n * p.H * p.W;
+      r.flops = 2.0 * 9 * r.cin * r.cout * px;
+      r.bytes = 4.0 * px * (r.cin + r.cout);
+      sr::prof_begin(stream, r);
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * d->n), dim3(256), lds, stream, p);
+    if (prof) sr::prof_end(stream);
+    SR_CHECK_LAUNCH("conv_fewcout_f32 launch");
+    return SR_OK;
+  }
   if (d->out_nchw) return launch<1, PT, 3, true>(p, d->n, groups, stream, d);
   if (gc == 64) return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
   // 32-cout groups: 16-row tiles (PT = 4) halve the weight refill per MFMA (measured +2.5..7 % on the RDB conv1-4
@@ -468,5 +618,6 @@ extern "C" const char* sr_kernel_name(int id) {
                                   "wgrad3x3_f32_kernelILi2ELi1ELi1E"};
   if (id >= 8 && id < 13) return wnames[id - 8];
   if (id == 13) return "conv_f32_kernelILi1ELi4ELi3ELb0E";
+  if (id == 14) return "conv_fewcout_f32_kernelILi3E";
   return (id >= 0 && id < 8) ? names[id] : "";
 }

@@ -5,18 +5,18 @@
 
 #include <vector>
 
-template <int COT, int PT, int ABL>
+template <int COT, int PT, int ABL, int NW = 4>
 float run(const ConvParams& p, int n, int iters, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<COT, PT, 3>();
-  auto kern = conv_f32_kernel<COT, PT, 3, false, ABL>;
+  constexpr int lds = conv_lds_bytes<COT, PT, 3, NW>();
+  auto kern = conv_f32_kernel<COT, PT, 3, false, ABL, NW>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid(p.tiles_x * p.tiles_y * n, 1);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p);
   hipEventRecord(a, st);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p);
   hipEventRecord(b, st);
   hipEventSynchronize(b);
   float ms;
@@ -57,6 +57,9 @@ int main() {
         p.tiles_y = H / 16;
         report("PT4 full", run<1, 4, 0>(p, N, 20, st));
         report("PT4 no-refill no-barrier", run<1, 4, 3>(p, N, 20, st));
+        report("8 waves PT2 full", run<1, 2, 0, 8>(p, N, 20, st));
+        p.tiles_y = H / 32;
+        report("8 waves PT4 full", run<1, 4, 0, 8>(p, N, 20, st));
       } else {
         report("PT2 full", run<2, 2, 0>(p, N, 20, st));
         report("PT2 no-refill", run<2, 2, 1>(p, N, 20, st));
@@ -67,6 +70,8 @@ int main() {
         p.tiles_y = H / 16;
         report("PT4 full", run<2, 4, 0>(p, N, 20, st));
         report("PT4 no-refill no-barrier", run<2, 4, 3>(p, N, 20, st));
+        report("8 waves PT2 full", run<2, 2, 0, 8>(p, N, 20, st));
+        report("8 waves PT2 no-refill", run<2, 2, 1, 8>(p, N, 20, st));
       }
       hipFree(in); hipFree(out); hipFree(w);
     }
