@@ -295,3 +295,76 @@ extern "C" int sr_conv4x4s2_pack_f32(const float* weight, const float* bias, int
   }
   return SR_OK;
 }
+
+
+// ---- data-gradient weights of a residual dense block as a TRANSPOSED dense block ---------------------------
+// Backward of ResidualDenseBlock.forward (rrdbnet_arch.py:32-39) is itself a dense block over the gradient concat
+// [dY5 | dY4 | dY3 | dY2 | dY1]:  the gradient of slice s (s = 4..1: x4..x1, s = 0: x) is ONE 3x3 conv whose input
+// is every dY_k with k > s and whose weights are W_k[:, slice s]^T with flipped taps (W5's part carries the 0.2 /
+// 0.04 residual scale).  Same shapes as the forward convs (64->32, 96->32, 128->32, 160->32, 192->64), every
+// output written once: no read-modify-write accumulation, no K = 288 launches.
+namespace {
+struct DensePackParams {
+  const float* w[5];  // conv1..conv5 OIHW
+  float* out;
+  int nf, gc, nfp, gcp, s;
+  float scale5;
+};
+// thread per (k, co, ci_local, tap) with k = s+1..5; element counts are prefix-summed on the fly
+__global__ void pack_dense_dgrad_kernel(const DensePackParams p) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slice = p.s == 0 ? p.nf : p.gc;
+  const int slice0 = p.s == 0 ? 0 : p.nf + (p.s - 1) * p.gc;
+  const int cin_pad = p.nfp + (4 - p.s) * p.gcp;  // D-order input channels of this step (s >= 1: dY5..dY_{s+1}); s = 0: all
+  const int cinp = p.s == 0 ? p.nfp + 4 * p.gcp : cin_pad;
+  for (int k = 5; k > p.s; --k) {
+    const int cout_k = k == 5 ? p.nf : p.gc, cin_k = p.nf + (k - 1) * p.gc;
+    const long long cnt = (long long)cout_k * slice * 9;
+    if (i < cnt) {
+      const int tap = (int)(i % 9);
+      const int cil = (int)((i / 9) % slice);
+      const int co = (int)(i / (9LL * slice));
+      float v = p.w[k - 1][((long long)co * cin_k + slice0 + cil) * 9 + tap];
+      if (k == 5) v *= p.scale5;
+      const int pos = k == 5 ? co : p.nfp + (4 - k) * p.gcp + co;
+      const int gcw = (((slice + 31) / 32 * 32) % 64 == 0) ? 64 : 32;
+      const int cbs = cinp / 8;
+      const int g = cil / gcw, col = cil % gcw;
+      p.out[((((long long)g * cbs + (pos >> 3)) * 9 + (8 - tap)) * gcw + col) * 8 + (pos & 7)] = v;
+      return;
+    }
+    i -= cnt;
+  }
+}
+}  // namespace
+
+namespace sr {
+size_t rdb_dgrad_step_floats(int nf, int gc, int s) {
+  const int nfp = (nf + 7) / 8 * 8, gcp = (gc + 7) / 8 * 8;
+  const int slice = s == 0 ? nf : gc;
+  const int cinp = nfp + (4 - s) * gcp;
+  return sr_conv3x3_packed_weight_floats(slice, cinp);
+}
+int rdb_pack_dgrad_step(const float* const w[5], int nf, int gc, int s, float scale5, float* out, hipStream_t stream) {
+  const size_t floats = rdb_dgrad_step_floats(nf, gc, s);
+  if (hipMemsetAsync(out, 0, floats * sizeof(float), stream) != hipSuccess) {
+    set_error("rdb_pack_dgrad_step: memset failed");
+    return SR_ELAUNCH;
+  }
+  DensePackParams p;
+  for (int i = 0; i < 5; ++i) p.w[i] = w[i];
+  p.out = out;
+  p.nf = nf;
+  p.gc = gc;
+  p.nfp = (nf + 7) / 8 * 8;
+  p.gcp = (gc + 7) / 8 * 8;
+  p.s = s;
+  p.scale5 = scale5;
+  const int slice = s == 0 ? nf : gc;
+  long long total = 0;
+  for (int k = 5; k > s; --k) total += (long long)(k == 5 ? nf : gc) * slice * 9;
+  hipLaunchKernelGGL(pack_dense_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  SR_CHECK_LAUNCH("pack_dense_dgrad");
+  return SR_OK;
+}
+}  // namespace sr

@@ -33,6 +33,7 @@ struct ConvPlan {
 struct NetPlan {
   int nfp, gcp, cin0, cin0_pad, unshuffle;
   std::vector<ConvPlan> convs;  // state_dict order
+  std::vector<size_t> rdb_dg;   // [rdb][step s = 0..4]: transposed-dense-block images in the data-gradient blob
   size_t packed_floats, dgrad_floats;
 };
 
@@ -67,8 +68,15 @@ bool make_plan(const sr_rrdbnet_cfg* c, NetPlan* P) {
   add(nf, P->cin0, P->cin0, 0);  // conv_first
   for (int b = 0; b < c->num_block; ++b)
     for (int r = 0; r < 3; ++r) {
+      const size_t dg_before = dg;
       for (int k = 1; k <= 4; ++k) add(gc, nf + (k - 1) * gc, nf, gc);  // conv1..conv4 (:21-24)
       add(nf, nf + 4 * gc, nf, gc);                                     // conv5 (:25)
+      // the five per-conv data-gradient images are replaced by the five step images of the transposed dense block
+      dg = dg_before;
+      for (int s = 0; s < 5; ++s) {
+        P->rdb_dg.push_back(dg);
+        dg += sr::align_up(sr::rdb_dgrad_step_floats(nf, gc, s), 64);
+      }
     }
   add(nf, nf, nf, 0);             // conv_body
   add(nf, nf, nf, 0);             // conv_up1
@@ -390,12 +398,24 @@ extern "C" int sr_rrdbnet_pack_dgrad_f32(const sr_rrdbnet_cfg* cfg, const float*
   NetPlan P;
   SR_CHECK_ARG(make_plan(cfg, &P), "sr_rrdbnet_pack_dgrad_f32: bad config");
   SR_CHECK_ARG(host_params && packed_dgrad, "sr_rrdbnet_pack_dgrad_f32: null argument");
+  const int n_rdb = 3 * cfg->num_block;
   for (size_t i = 0; i < P.convs.size(); ++i) {
     const ConvPlan& cp = P.convs[i];
     SR_CHECK_ARG(host_params[2 * i], "sr_rrdbnet_pack_dgrad_f32: null parameter %zu", i);
+    if (i >= 1 && i < 1 + 5 * (size_t)n_rdb) continue;  // dense-block convs: packed per step below
     int rc = sr_conv3x3_pack_f32(host_params[2 * i], nullptr, cp.cout, cp.cin, cp.first_seg, cp.seg, 1,
                                  packed_dgrad + cp.dg_off, nullptr, stream);
     if (rc) return rc;
+  }
+  for (int q = 0; q < n_rdb; ++q) {
+    const float* w[5];
+    for (int k = 0; k < 5; ++k) w[k] = host_params[2 * (1 + 5 * q + k)];
+    const float scale5 = (q % 3 == 2) ? 0.04f : 0.2f;  // x5*0.2 (+ the RRDB's *0.2 for rdb3), rrdbnet_arch.py:39,63
+    for (int s = 0; s < 5; ++s) {
+      int rc = sr::rdb_pack_dgrad_step(w, cfg->num_feat, cfg->num_grow_ch, s, scale5, packed_dgrad + P.rdb_dg[q * 5 + s],
+                                       (hipStream_t)stream);
+      if (rc) return rc;
+    }
   }
   return SR_OK;
 }
@@ -544,35 +564,59 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
   int gi = 0;  // G buffer holding the gradient wrt the current block output in its first nfb blocks
   rc = dgrad(i_body, B.dtrunk, feat_ns, h, w, B.g[gi], cat_ns, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0, nullptr, 0, 0, 0);
   if (rc) return rc;
-  // body, in reverse
+  // body, in reverse.  Each RDB's data gradient is a transposed dense block over the gradient concat buffer
+  // D = [dY5 | dY4 | dY3 | dY2 | dY1] (layout.hip: pack_dense_dgrad): step s reads D[0 : nfp+(4-s)*gcp) and writes
+  // slice s once, with the LeakyReLU backward of x_s in its epilogue; step 0 writes dL/dx into the next buffer.
+  auto step = [&](int q, int sidx, const float* in, int cin_pad, float* out, int cout, const float* r1, float b1,
+                  const float* r2, float b2, const float* mask, int mask_cbn) -> int {
+    sr_conv3x3_desc d = {};
+    d.in = in;
+    d.in_img_stride = cat_ns;
+    d.cin_pad = cin_pad;
+    d.cin_real = cin_pad;
+    d.in_h = h;
+    d.in_w = w;
+    d.wpacked = packed_dgrad + P.rdb_dg[q * 5 + sidx];
+    d.cout = cout;
+    d.out = out;
+    d.out_img_stride = cat_ns;
+    d.n = n;
+    d.act_slope = 1.f;
+    d.alpha = 1.f;
+    d.res1 = r1;
+    d.res1_img_stride = cat_ns;
+    d.beta1 = b1;
+    d.res2 = r2;
+    d.res2_img_stride = cat_ns;
+    d.beta2 = b2;
+    d.mask_src = mask;
+    d.mask_img_stride = cat_ns;
+    d.mask_cb0 = 0;
+    d.mask_cbn = mask_cbn;
+    d.mask_slope = 0.2f;
+    return sr_conv3x3_f32(&d, stream);
+  };
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const float* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
       const int q = 3 * b + r;
       const float* cat = S.cat[q];
-      const float* dout = B.g[gi];
-      float* G = B.g[(gi + 1) & 3];
-      const int c5 = 1 + 5 * q + 4;
-      // out = 0.2*x5 + x; for rdb3 the block output is further scaled by 0.2 into the RRDB output (:39, :63)
+      float* D = B.g[gi];                  // D[0:nf] = dL/d(block output), written by the previous step 0 / conv_body
+      float* Dn = B.g[(gi + 1) & 3];
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
-      rc = wgrad(c5, cat, cat_ns, h, w, 0, dout, cat_ns, s5);
+      rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);  // conv5: dY5 = s5 * D[0:nf]
       if (rc) return rc;
-      // G[0:192] = s5*dgrad5(dout); G[0:64] += sres*dout (+ dL/d(RRDB out) once the RRDB input is reached);
-      // LeakyReLU backward of x4 on its slice.
-      rc = dgrad(c5, dout, cat_ns, h, w, G, cat_ns, s5, dout, cat_ns, sres, r == 0 ? d_rrdb : nullptr, cat_ns, 1.f, 0,
-                 cat + (long long)(P.nfp + 3 * P.gcp) * hw, cat_ns, nfb + 3 * gcb, gcb);
-      if (rc) return rc;
-      for (int k = 4; k >= 1; --k) {
-        const int ck = 1 + 5 * q + (k - 1);
-        const float* dyk = G + (long long)(P.nfp + (k - 1) * P.gcp) * hw;  // dL/d(conv_k pre-activation)
-        rc = wgrad(ck, cat, cat_ns, h, w, 0, dyk, cat_ns, 1.f);
+      for (int sl = 4; sl >= 1; --sl) {  // dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k
+        float* dys = D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw;
+        rc = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, dys, cfg->num_grow_ch, nullptr, 0.f, nullptr, 0.f,
+                  cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
         if (rc) return rc;
-        const bool has_mask = k >= 2;  // x_{k-1} is an activation output; x itself is not
-        rc = dgrad(ck, dyk, cat_ns, h, w, G, cat_ns, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 1,
-                   has_mask ? cat + (long long)(P.nfp + (k - 2) * P.gcp) * hw : nullptr, cat_ns, nfb + (k - 2) * gcb,
-                   has_mask ? gcb : 0);
+        rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, dys, cat_ns, 1.f);
         if (rc) return rc;
       }
+      // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
+      rc = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
+      if (rc) return rc;
       gi = (gi + 1) & 3;
     }
   }

@@ -12,6 +12,8 @@ void set_error(const char* fmt, ...);
 bool prof_on();
 void prof_begin(hipStream_t s, const sr_launch_record& r);
 void prof_end(hipStream_t s);
+size_t rdb_dgrad_step_floats(int nf, int gc, int s);
+int rdb_pack_dgrad_step(const float* const w[5], int nf, int gc, int s, float scale5, float* out, hipStream_t stream);
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
 
 #define SR_CHECK_ARG(cond, ...)            \
