@@ -151,17 +151,47 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
       const char* xb[KT];
 #pragma unroll
       for (int dy = 0; dy < KT; ++dy) xb[dy] = xring + ((row + dy) % NXR) * XROWB + b_lane + s0 * 2 * XCH * 4;
+      // Software pipeline over the pixel-pair k-steps: the operands of step s+1 (1 dY value, KT*(KT-1) new X values —
+      // the dx = 0 column of step s+1 is the dx = 2 column of step s) are loaded BEFORE the KT*KT MFMAs of step s,
+      // so their LDS latency hides behind 576 MFMA cycles instead of stalling every few MFMAs (2 waves per SIMD only).
+      float a_cur, b_cur[KT][KT];
+      a_cur = *(const float*)ya;
+#pragma unroll
+      for (int dy = 0; dy < KT; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < KT; ++dx) b_cur[dy][dx] = *(const float*)(xb[dy] + dx * XCH * 4);
 #pragma unroll
       for (int s = 0; s < SN; ++s) {
-        const float a = *(const float*)(ya + s * 2 * YCH * 4);
-        bsum += a;
+        float a_nxt = 0.f, b_nxt[KT][KT];
+        if (s + 1 < SN) {
+          a_nxt = *(const float*)(ya + (s + 1) * 2 * YCH * 4);
+#pragma unroll
+          for (int dy = 0; dy < KT; ++dy) {
+            if (KT == 3) {
+              b_nxt[dy][0] = b_cur[dy][2];
+#pragma unroll
+              for (int dx = 1; dx < KT; ++dx) b_nxt[dy][dx] = *(const float*)(xb[dy] + ((s + 1) * 2 + dx) * XCH * 4);
+            } else {
+#pragma unroll
+              for (int dx = 0; dx < KT; ++dx) b_nxt[dy][dx] = *(const float*)(xb[dy] + ((s + 1) * 2 + dx) * XCH * 4);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc otherwise sinks the loads)
+        bsum += a_cur;
 #pragma unroll
         for (int dy = 0; dy < KT; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < KT; ++dx) {
-            const float b = *(const float*)(xb[dy] + (s * 2 + dx) * XCH * 4);
-            acc[dy * KT + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[dy * KT + dx], 0, 0, 0);
-          }
+          for (int dx = 0; dx < KT; ++dx)
+            acc[dy * KT + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[dy][dx], acc[dy * KT + dx], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < SN) {
+          a_cur = a_nxt;
+#pragma unroll
+          for (int dy = 0; dy < KT; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < KT; ++dx) b_cur[dy][dx] = b_nxt[dy][dx];
+        }
       }
     }
     __syncthreads();
