@@ -453,6 +453,32 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
   }
 }
 
+// sum over the cropped region of (round(clamp(a,0,1)*255) - round(clamp(b,0,1)*255))^2 for image n = blockIdx.y
+__global__ __launch_bounds__(256) void psnr_sse_kernel(const float* __restrict__ a, const float* __restrict__ b, int c, int h,
+                                                       int w, int crop, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const int n = blockIdx.y;
+  const int hh = h - 2 * crop, ww = w - 2 * crop;
+  const long long total = (long long)c * hh * ww;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const int x = (int)(i % ww), y = (int)((i / ww) % hh), ch = (int)(i / ((long long)ww * hh));
+    const long long idx = (((long long)n * c + ch) * h + (y + crop)) * w + (x + crop);
+    const float qa = rintf(fminf(fmaxf(a[idx], 0.f), 1.f) * 255.f), qb = rintf(fminf(fmaxf(b[idx], 0.f), 1.f) * 255.f);
+    s += (qa - qb) * (qa - qb);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(long long)n * gridDim.x + blockIdx.x] = s;
+}
+__global__ void psnr_finalize_kernel(const float* part, int nparts, float* out) {
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(long long)n * nparts + k];
+    out[n] = s;
+  }
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -723,5 +749,18 @@ extern "C" int sr_add_f32(const float* a, const float* b, float* out, int64_t n,
   SR_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "sr_add_f32: n must be a positive multiple of 4");
   hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 4)), dim3(256), 0, stream, a, b, out, (long long)(n / 4));
   SR_CHECK_LAUNCH("add");
+  return SR_OK;
+}
+
+extern "C" int sr_psnr_sse_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sse,
+                               void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(a && b && sse && ws && n > 0 && c > 0 && crop_border >= 0 && h > 2 * crop_border && w > 2 * crop_border,
+               "sr_psnr_sse_f32: bad argument");
+  const int parts = 64;
+  SR_CHECK_ARG(ws_bytes >= (size_t)n * parts * sizeof(float), "sr_psnr_sse_f32: workspace too small");
+  hipLaunchKernelGGL(psnr_sse_kernel, dim3(parts, n), dim3(256), 0, stream, a, b, c, h, w, crop_border, (float*)ws);
+  hipLaunchKernelGGL(psnr_finalize_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, parts, sse);
+  SR_CHECK_LAUNCH("psnr_sse");
   return SR_OK;
 }

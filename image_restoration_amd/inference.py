@@ -36,9 +36,8 @@ def load_generator(args, device):
     net = build_network(dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=args.scale, num_feat=args.num_feat,
                              num_block=args.num_block, num_grow_ch=args.num_grow_ch))
     if args.model_path:
-        ck = torch.load(args.model_path, map_location='cpu', weights_only=False)
-        ck = ck.get('params_ema', ck.get('params', ck))
-        net.load_state_dict({k[7:] if k.startswith('module.') else k: v for k, v in ck.items()}, strict=True)
+        from .utils.checkpoint import load_generator_weights
+        load_generator_weights(net, args.model_path, strict=True)  # BasicSR files and official ESRGAN key names
     return net.to(device).eval()
 
 

@@ -1,0 +1,60 @@
+"""PSNR as the reference computes it during validation (basicsr/metrics/psnr_ssim.py:8-46 called from
+sr_model.py:135-184 on ``tensor2img`` outputs): uint8-rounded images, optional border crop, 20*log10(255/sqrt(mse)).
+
+``calculate_psnr`` is the host (numpy) form with the reference's signature; ``psnr_device`` keeps the SR output on the
+GPU: clamp, *255, round (half-to-even like np.round), crop and the squared-error sum are one HIP reduction
+(sr_psnr_sse_f32), so validation needs no device->host image copy."""
+import math
+
+import numpy as np
+import torch
+
+from ..utils.registry import METRIC_REGISTRY
+
+
+def _to_y(img):
+    # BT.601 luma of a BGR float image in [0, 255] (metric_util.to_y_channel -> bgr2ycbcr(y_only=True))
+    img = img.astype(np.float32) / 255.
+    y = np.dot(img, [24.966, 128.553, 65.481]) + 16.0
+    return y[..., None]
+
+
+@METRIC_REGISTRY.register()
+def calculate_psnr(img1, img2, crop_border, input_order='HWC', test_y_channel=False):
+    assert img1.shape == img2.shape, f'Image shapes are differnet: {img1.shape}, {img2.shape}.'
+    if input_order not in ['HWC', 'CHW']:
+        raise ValueError(f'Wrong input_order {input_order}. Supported input_orders are "HWC" and "CHW"')
+    if input_order == 'CHW':
+        img1, img2 = img1.transpose(1, 2, 0), img2.transpose(1, 2, 0)
+    if img1.ndim == 2:
+        img1, img2 = img1[..., None], img2[..., None]
+    img1, img2 = img1.astype(np.float64), img2.astype(np.float64)
+    if crop_border != 0:
+        img1 = img1[crop_border:-crop_border, crop_border:-crop_border, ...]
+        img2 = img2[crop_border:-crop_border, crop_border:-crop_border, ...]
+    if test_y_channel:
+        img1, img2 = _to_y(img1), _to_y(img2)
+    mse = np.mean((img1 - img2)**2)
+    if mse == 0:
+        return float('inf')
+    return 20. * np.log10(255. / np.sqrt(mse))
+
+
+def psnr_device(sr, gt, crop_border=0):
+    """PSNR per image of NCHW float tensors in [0, 1] on the HIP device, with tensor2img's quantisation."""
+    import ctypes as C
+    from .. import _lib
+    from ..hip_ops import scratch
+    assert sr.shape == gt.shape and sr.dim() == 4 and sr.is_cuda
+    lib = _lib.load()
+    sr, gt = sr.contiguous().float(), gt.contiguous().float()
+    n, c, h, w = sr.shape
+    out = torch.empty(n, dtype=torch.float32, device=sr.device)
+    wsb = lib.sr_reduce_workspace_bytes(8) * max(n, 1)
+    ws = scratch(sr.device, wsb)
+    with torch.cuda.device(sr.device):
+        _lib.check(lib.sr_psnr_sse_f32(sr.data_ptr(), gt.data_ptr(), n, c, h, w, crop_border, out.data_ptr(), ws.data_ptr(), wsb,
+                                       torch.cuda.current_stream(sr.device).cuda_stream), 'sr_psnr_sse_f32')
+    count = c * (h - 2 * crop_border) * (w - 2 * crop_border)
+    mse = out.double().cpu().numpy() / count
+    return [float('inf') if m == 0 else 20. * math.log10(255. / math.sqrt(m)) for m in mse]

@@ -214,6 +214,12 @@ int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float*
 /* out = a + b (skip connections of UNetDiscriminatorSN); n multiple of 4. */
 int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* Validation PSNR numerator (psnr_ssim.py:8-46 on tensor2img outputs, img_util.py:38-94): per image n,
+ * sse[n] = sum over channels and the border-cropped region of (round(clamp(a,0,1)*255) - round(clamp(b,0,1)*255))^2,
+ * a, b NCHW float in [0,1].  ws >= n*64 floats. */
+int sr_psnr_sse_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sse, void* ws,
+                    size_t ws_bytes, void* stream);
+
 /* out[0] = mean(x) */
 int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 /* L1Loss(loss_weight, reduction='mean') (losses.py:80-106): loss[0] = weight*mean|pred-target|;

@@ -75,3 +75,16 @@ def test_train_entry_point_runs_saves_and_resumes(cuda, tmp_path):
     assert model2.optimizer_g.step_count == 6 and model2.optimizer_d.step_count == 6
     ck = torch.load(exp / 'models' / 'net_g_latest.pth', weights_only=False)
     assert set(ck) == {'params', 'params_ema'}
+
+
+def test_device_psnr_matches_host(cuda):
+    from image_restoration_amd.metrics import calculate_psnr, psnr_device
+    from image_restoration_amd.utils.img_util import tensor2img
+    sr = torch.from_numpy(synth.signed_input(1, (3, 3, 40, 52), 0.7) + 0.5).clamp(-0.2, 1.2)
+    gt = torch.from_numpy(synth.uniform_input(2, (3, 3, 40, 52)))
+    got = psnr_device(sr.to(cuda), gt.to(cuda), crop_border=4)
+    for i in range(3):
+        a = tensor2img(sr[i:i + 1], rgb2bgr=True, min_max=(0, 1))
+        b = tensor2img(gt[i:i + 1], rgb2bgr=True, min_max=(0, 1))
+        assert abs(got[i] - calculate_psnr(a, b, 4)) < 1e-4
+    assert psnr_device(gt.to(cuda), gt.to(cuda))[0] == float('inf')

@@ -71,3 +71,34 @@ def test_tile_plan_covers_frame_exactly_once():
             assert y0 - py0 <= pad and py1 - y1 <= pad
         assert (cover == 1).all()
     assert len(plan_tiles(2160, 3840, 512, 16)) == 40  # BASELINE config 5: 5 x 8 cells
+
+
+def test_official_esrgan_key_map_roundtrip():
+    import image_restoration_amd as ira
+    from image_restoration_amd.utils import checkpoint as ck
+    net = ira.build_network(dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, num_feat=16, num_block=2, num_grow_ch=8))
+    sd = net.state_dict()
+    official = {ck.basicsr_to_official_key(k): v.clone() + 1 for k, v in sd.items()}
+    assert 'RRDB_trunk.1.RDB3.conv5.weight' in official and 'trunk_conv.bias' in official and 'upconv2.weight' in official
+    assert 'HRconv.weight' in official and 'conv_first.weight' in official and 'conv_last.bias' in official
+    assert ck.is_official_esrgan(official) and not ck.is_official_esrgan(sd)
+    assert list(ck.convert_official_esrgan(official).keys()) == list(sd.keys())
+    ck.load_generator_weights(net, {'module.' + k: v for k, v in official.items()})
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k] + 1) if False else torch.allclose(v, official[ck.basicsr_to_official_key(k)])
+    ck.load_generator_weights(net, {'params': {k: v * 0 for k, v in sd.items()}, 'params_ema': sd}, prefer='params')
+    assert float(next(net.parameters()).abs().sum()) == 0.0
+
+
+def test_psnr_host_matches_definition():
+    from image_restoration_amd.metrics import calculate_psnr
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (20, 24, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a[4:-4, 4:-4].astype(np.float64) - b[4:-4, 4:-4].astype(np.float64))**2)
+    assert abs(calculate_psnr(a, b, 4) - 20 * np.log10(255 / np.sqrt(mse))) < 1e-12
+    assert calculate_psnr(a, a, 0) == float('inf')
+    assert abs(calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), 4, input_order='CHW') - calculate_psnr(a, b, 4)) < 1e-12
+    assert np.isfinite(calculate_psnr(a, b, 0, test_y_channel=True))
+    with pytest.raises(ValueError):
+        calculate_psnr(a, b, 0, input_order='XYZ')
