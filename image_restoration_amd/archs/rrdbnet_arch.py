@@ -71,6 +71,9 @@ class RRDBNet(nn.Module):
         self._packed_dg_key = None
         self._grad_sink = None    # set by optim.FlatAdam: gradients accumulate straight into its arena
         self._workspaces = {}
+        self.compute_dtype = 'fp32'  # 'bf16' selects the reduced-precision inference kernels (not in the reference)
+        self._packed_h = None
+        self._packed_h_key = None
 
     # ------------------------------------------------------------------ HIP plumbing
     def invalidate_packed(self):
@@ -78,6 +81,15 @@ class RRDBNet(nn.Module):
         arena without bumping tensor versions)."""
         self._packed_key = None
         self._packed_dg_key = None
+        self._packed_h_key = None
+
+    def set_compute_dtype(self, dtype):
+        """'fp32' (reference numerics, default) or 'bf16' (inference only: bf16 activations/weights on
+        v_mfma_f32_32x32x16_bf16 with fp32 accumulation; training always runs fp32)."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        self.compute_dtype = dtype
+        return self
 
     def _cfg(self):
         # scale other than 1/2/4 behaves like 4 in the reference (no unshuffle, :106-111)
@@ -166,7 +178,39 @@ class RRDBNet(nn.Module):
             stream = torch.cuda.current_stream().cuda_stream
             return self._launch(lib, cfg, x, n, h, w, stream)
 
+    def _launch_bf16(self, lib, cfg, x, n, h, w, stream):
+        params = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed_h is None or key != self._packed_h_key:
+            nb = lib.sr_rrdbnet_packed_bytes_bf16(C.byref(cfg))
+            if self._packed_h is None or self._packed_h.numel() != nb or self._packed_h.device != x.device:
+                self._packed_h = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            for p in params:
+                if p.device != x.device or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.SrHipError('RRDBNet parameters must be contiguous fp32 on the input device')
+            ptrs = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            _lib.check(lib.sr_rrdbnet_pack_bf16(C.byref(cfg), ptrs, self._packed_h.data_ptr(), stream),
+                       'sr_rrdbnet_pack_bf16')
+            self._packed_h_key = key
+        nbytes = lib.sr_rrdbnet_workspace_bytes_bf16(C.byref(cfg), n, h, w)
+        if nbytes == 0:
+            raise _lib.SrHipError(f'sr_rrdbnet_workspace_bytes_bf16 returned 0 for input {h}x{w}')
+        wkey = ('bf16', n, h, w, str(x.device))
+        ws = self._workspaces.get(wkey)
+        if ws is None:
+            self._workspaces.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            self._workspaces[wkey] = ws
+        up = {4: 4, 2: 2, 1: 1}[cfg.scale]
+        y = torch.empty((n, self.num_out_ch, h * up, w * up), dtype=torch.float32, device=x.device)
+        _lib.check(
+            lib.sr_rrdbnet_forward_bf16(C.byref(cfg), self._packed_h.data_ptr(), x.data_ptr(), y.data_ptr(), n, h, w,
+                                        ws.data_ptr(), nbytes, stream), 'sr_rrdbnet_forward_bf16')
+        return y
+
     def _launch(self, lib, cfg, x, n, h, w, stream):
+        if self.compute_dtype == 'bf16':
+            return self._launch_bf16(lib, cfg, x, n, h, w, stream)
         packed = self._ensure_packed(lib, cfg, stream)
         ws, nbytes = self._workspace(lib, cfg, n, h, w, x.device)
         up = {4: 4, 2: 2, 1: 1}[cfg.scale]

@@ -1,0 +1,282 @@
+// bf16 3x3 convolution on v_mfma_f32_32x32x16_bf16 (gfx950) — inference path of the generator.
+//
+// The reference has no reduced precision at all; BASELINE configs 3-4 name bf16, so this is a build
+// extension whose parity is declared against the fp32 oracle with its own tolerance (tests/test_bf16_gpu.py).
+//
+// Layout CB16: __bf16 feat[N][C/16][H][W][16] — one pixel of one 16-channel block is again 32 bytes, so the LDS
+// images, the LDS-DMA staging and every address of the fp32 kernel (conv_f32.hip) carry over byte for byte:
+//   X tile [TH+2][34][32 B], W image [9][32*COT][32 B], chunk = one 16-channel block.
+// One MFMA (K = 16) consumes a whole chunk of one tap: lane (pixel j, half h) reads 16 B = channels 8h..8h+7 as the B
+// operand, lane (cout i, half h) the matching 16 B of the weight image as the A operand; accumulators are fp32 and
+// have the fp32 kernel's layout (pixel on the lane, 4 consecutive couts per register quad), so the epilogue is the
+// same with an 8-byte bf16x4 store.  Per chunk a wave issues 9*(COT+PT) ds_read_b128 for 9*COT*PT MFMAs of 32
+// cycles: with COT = 2, PT = 4 that is 0.75 reads per MFMA (LDS limit: 2).  The kernel is fed by L2->LDS traffic:
+// 37.6 KB per 9.4 MFLOP chunk of a 16x32x64 tile = 251 FLOP/B.
+#include "sr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float g_zero_line_h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct ConvParamsH {
+  const char* in;     // CB16 bf16
+  const char* w;      // packed bf16 image [group][cin/16][tap][32*COT][16]
+  const float* bias;  // fp32 [cout pad 32] or null
+  char* out;          // CB16 bf16, or NCHW fp32 when NCHW_OUT
+  const char* res1;
+  const char* res2;
+  long long in_nb, out_nb, res1_nb, res2_nb;  // image strides in BYTES
+  int cin_blocks;   // Cin / 16
+  int cout_blocks;  // valid 16-channel blocks of the destination (ceil(cout/16))
+  int cout;
+  int in_h, in_w, H, W, tiles_x, tiles_y;
+  int src_shift;    // 1: nearest x2 upsample on the fly
+  float slope, alpha, beta1, beta2;
+};
+
+__device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int COT, int PT, bool NCHW_OUT>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TH = 4 * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+  constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
+  constexpr int NXU = XBYTES / 1024, NWU = 9 * COT;
+  constexpr int WBYTES = NWU * 1024, STAGE = XBYTES + WBYTES;
+  constexpr int NXR = (NXU + 3) / 4, NWR = (NWU + 3) / 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int cog = blockIdx.y;
+  const int x0 = tx * 32, y0 = ty * TH;
+  const long long plane_b = (long long)p.in_h * p.in_w * 32;  // bytes of one 16-channel block plane
+  const char* in_n = p.in + (long long)n * p.in_nb;
+  const char* wg = p.w + (size_t)cog * p.cin_blocks * WBYTES;
+
+  int xoff[NXR];  // byte offset inside a block plane; -1 = zero padding
+#pragma unroll
+  for (int r = 0; r < NXR; ++r) {
+    const int u = r * 4 + wave;
+    const int q = u * 64 + lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const int sy = gy >> p.src_shift, sx = gx >> p.src_shift;
+    xoff[r] = valid ? ((sy * p.in_w + sx) * 32 + half * 16) : -1;
+  }
+
+  auto stage = [&](int buf, int cb) {
+    char* xs = smem + buf * STAGE;
+    char* ws = xs + XBYTES;
+    const char* plane = in_n + (size_t)cb * plane_b;
+#pragma unroll
+    for (int r = 0; r < NXR; ++r) {
+      const int u = r * 4 + wave;
+      if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : (const void*)g_zero_line_h, xs + u * 1024);
+    }
+    const char* wsrc = wg + (size_t)cb * WBYTES + lane * 16;
+#pragma unroll
+    for (int r = 0; r < NWR; ++r) {
+      const int u = r * 4 + wave;
+      if (u < NWU) glds16h(wsrc + u * 1024, ws + u * 1024);
+    }
+  };
+
+  f32x16 acc[COT][PT];
+#pragma unroll
+  for (int a = 0; a < COT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int xlane = ((wave * PT) * XROW + j) * 32 + h * 16;
+  const int wlane = j * 32 + h * 16;
+
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * STAGE + xlane;
+    const char* ws = smem + buf * STAGE + XBYTES + wlane;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int tap = dy * 3 + dx;
+        bf16x8 a[COT], b[PT];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) a[c] = *(const bf16x8*)(ws + (tap * COT + c) * 1024);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) b[r] = *(const bf16x8*)(xs + ((r + dy) * XROW + dx) * 32);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int r = 0; r < PT; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], b[r], acc[c][r], 0, 0, 0);
+      }
+  };
+
+  const int nchunk = p.cin_blocks;
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    compute(c & 1);
+    __syncthreads();
+  }
+
+  // epilogue: bias, LeakyReLU, residual scale-adds in fp32; bf16x4 (8-byte) stores into CB16, or fp32 NCHW
+  const int x = x0 + j;
+  const long long HW = (long long)p.H * p.W;
+#pragma unroll
+  for (int r = 0; r < PT; ++r) {
+    const int y = y0 + wave * PT + r;
+    if (y >= p.H || x >= p.W) continue;
+    const long long pixoff = (long long)y * p.W + x;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co0 = (cog * COT + c) * 32 + g * 8 + h * 4;  // first of this lane's 4 couts
+        const int cb = co0 >> 4;
+        if (cb >= p.cout_blocks) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[c][r][g * 4 + e];
+        if (p.bias) v += *(const f32x4*)(p.bias + co0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        v *= p.alpha;
+        const long long off = ((cb * HW + pixoff) * 16 + (co0 & 15)) * 2;  // bytes
+        if (p.res1) {
+          const bf16x4 rv = *(const bf16x4*)(p.res1 + (long long)n * p.res1_nb + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.beta1 * (float)rv[e];
+        }
+        if (p.res2) {
+          const bf16x4 rv = *(const bf16x4*)(p.res2 + (long long)n * p.res2_nb + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.beta2 * (float)rv[e];
+        }
+        if constexpr (NCHW_OUT) {
+          float* on = (float*)(p.out + (long long)n * p.out_nb) + pixoff;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co0 + e < p.cout) on[(co0 + e) * HW] = v[e];
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+          *(bf16x4*)(p.out + (long long)n * p.out_nb + off) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int COT, int PT>
+constexpr int conv_bf16_lds() {
+  return 2 * ((((4 * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
+}
+
+template <int COT, int PT, bool NCHW_OUT>
+int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
+  constexpr int lds = conv_bf16_lds<COT, PT>();
+  static bool attr_set = false;
+  auto kern = conv_bf16_kernel<COT, PT, NCHW_OUT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      sr::set_error("sr_conv3x3_bf16: hipFuncSetAttribute(%d) failed", lds);
+      return SR_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  p.tiles_x = sr::cdiv(p.W, 32);
+  p.tiles_y = sr::cdiv(p.H, 4 * PT);
+  const bool prof = sr::prof_on();
+  if (prof) {
+    sr_launch_record r = {};
+    r.kernel_id = 16 + (COT - 1) * 2 + (PT == 4 ? 1 : 0) + (NCHW_OUT ? 4 : 0);
+    r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
+    r.cout = d->cout;
+    r.n = n;
+    r.h = p.H;
+    r.w = p.W;
+    const double px = (double)n * p.H * p.W;
+    r.flops = 2.0 * 9 * r.cin * r.cout * px;
+    r.bytes = 2.0 * ((double)n * p.in_h * p.in_w * r.cin + px * r.cout * (NCHW_OUT ? 2 : 1) + (d->res1 ? px * r.cout : 0) +
+                     (d->res2 ? px * r.cout : 0));
+    sr::prof_begin(stream, r);
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * n, groups), dim3(256), lds, stream, p);
+  if (prof) sr::prof_end(stream);
+  SR_CHECK_LAUNCH("conv_bf16 launch");
+  return SR_OK;
+}
+
+}  // namespace
+
+// d->in / out / res*: CB16 bf16 tensors (out: NCHW fp32 when out_nchw); *_img_stride in ELEMENTS of the tensor's dtype;
+// cin_pad multiple of 16; wpacked from sr_conv3x3_pack_bf16 (passed through the float* field); bpacked fp32.
+extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(d && d->in && d->wpacked && d->out, "sr_conv3x3_bf16: null argument");
+  SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 16 == 0, "sr_conv3x3_bf16: cin_pad=%d must be a multiple of 16", d->cin_pad);
+  SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_bf16: bad shape");
+  SR_CHECK_ARG(!d->accumulate && !d->mask_src && d->res_cbn == 0, "sr_conv3x3_bf16: accumulate/mask are fp32-path options");
+  SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 | (uintptr_t)d->res2 |
+                (uintptr_t)d->bpacked) % 16 == 0,
+               "sr_conv3x3_bf16: pointers must be 16-byte aligned");
+  ConvParamsH p = {};
+  p.in = (const char*)d->in;
+  p.w = (const char*)d->wpacked;
+  p.bias = d->bpacked;
+  p.out = (char*)d->out;
+  p.res1 = (const char*)d->res1;
+  p.res2 = (const char*)d->res2;
+  p.in_nb = d->in_img_stride * 2;
+  p.out_nb = d->out_img_stride * (d->out_nchw ? 4 : 2);
+  p.res1_nb = d->res1_img_stride * 2;
+  p.res2_nb = d->res2_img_stride * 2;
+  p.cin_blocks = d->cin_pad / 16;
+  p.cout_blocks = (d->cout + 15) / 16;
+  p.cout = d->cout;
+  p.in_h = d->in_h;
+  p.in_w = d->in_w;
+  p.H = d->upsample ? 2 * d->in_h : d->in_h;
+  p.W = d->upsample ? 2 * d->in_w : d->in_w;
+  p.src_shift = d->upsample ? 1 : 0;
+  p.slope = d->act_slope;
+  p.alpha = d->alpha;
+  p.beta1 = d->beta1;
+  p.beta2 = d->beta2;
+  SR_CHECK_ARG((long long)p.H * p.W * 32 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) < (1ll << 31),
+               "sr_conv3x3_bf16: image too large for 32-bit plane offsets");
+  const int cp = (d->cout + 31) / 32 * 32;
+  const int gc = (cp % 64 == 0) ? 64 : 32;
+  const int groups = cp / gc;
+  if (d->out_nchw) {
+    if (p.out_nb == 0) p.out_nb = (long long)d->cout * p.H * p.W * 4;
+    return gc == 64 ? launch_h<2, 2, true>(p, d->n, groups, stream, d) : launch_h<1, 2, true>(p, d->n, groups, stream, d);
+  }
+  const bool big = (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, 16) * d->n * groups >= 512 && p.H % 16 == 0;
+  if (gc == 64) return big ? launch_h<2, 4, false>(p, d->n, groups, stream, d) : launch_h<2, 2, false>(p, d->n, groups, stream, d);
+  return big ? launch_h<1, 4, false>(p, d->n, groups, stream, d) : launch_h<1, 2, false>(p, d->n, groups, stream, d);
+}

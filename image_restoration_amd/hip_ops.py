@@ -294,3 +294,112 @@ def conv4x4s2_wgrad(src, dy, cout, cin, *, scale=1.0, want_bias=False):
     with torch.cuda.device(dev):
         _lib.check(lib.sr_conv4x4s2_wgrad_f32(C.byref(d), _stream(dev)), 'sr_conv4x4s2_wgrad_f32')
     return dw, db
+
+
+# ------------------------------------------------------------------ bf16 (CB16) inference ops
+class CB16:
+    """A channel-blocked bf16 activation: storage ``buf`` [N, CB, H, W, 16] plus a channel-block window."""
+
+    def __init__(self, buf, cb0=0, cbn=None):
+        assert buf.dim() == 5 and buf.size(4) == 16 and buf.dtype == torch.bfloat16 and buf.is_contiguous()
+        self.buf, self.cb0 = buf, cb0
+        self.cbn = buf.size(1) - cb0 if cbn is None else cbn
+        assert 0 <= cb0 and cb0 + self.cbn <= buf.size(1)
+
+    @staticmethod
+    def zeros(n, channels, h, w, device):
+        return CB16(torch.zeros((n, (channels + 15) // 16, h, w, 16), dtype=torch.bfloat16, device=device))
+
+    n = property(lambda s: s.buf.size(0))
+    h = property(lambda s: s.buf.size(2))
+    w = property(lambda s: s.buf.size(3))
+    channels = property(lambda s: s.cbn * 16)
+    img_stride = property(lambda s: s.buf.size(1) * s.buf.size(2) * s.buf.size(3) * 16)
+    device = property(lambda s: s.buf.device)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.cb0 * self.h * self.w * 16 * 2
+
+    def slice(self, c0, c):
+        assert c0 % 16 == 0 and c % 16 == 0
+        return CB16(self.buf, self.cb0 + c0 // 16, c // 16)
+
+
+def nchw_to_cb16(x, unshuffle=1):
+    """fp32 NCHW -> CB16 bf16 (round-to-nearest-even), pixel_unshuffle fused — sr_nchw_to_cb16_bf16."""
+    lib = _lib.load()
+    _need_cuda(x, 'nchw_to_cb16')
+    x = x.contiguous().float()
+    n, c, sh, sw = x.shape
+    h, w = sh // unshuffle, sw // unshuffle
+    out = CB16.zeros(n, c * unshuffle * unshuffle, h, w, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.sr_nchw_to_cb16_bf16(x.data_ptr(), out.ptr, n, c, h, w, unshuffle, out.cbn, out.img_stride,
+                                            _stream(x.device)), 'sr_nchw_to_cb16_bf16')
+    return out
+
+
+def cb16_to_nchw(t, channels):
+    lib = _lib.load()
+    y = torch.empty((t.n, channels, t.h, t.w), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(lib.sr_cb16_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w,
+                                           _stream(t.device)), 'sr_cb16_to_nchw_f32')
+    return y
+
+
+class PackedConvBF16:
+    """bf16 MFMA weight image (+ fp32 bias) of one 3x3 conv — sr_conv3x3_pack_bf16."""
+
+    def __init__(self, weight, bias=None, first_seg=None, seg=0):
+        lib = _lib.load()
+        _need_cuda(weight, 'PackedConvBF16')
+        weight = weight.detach().contiguous().float()
+        cout, cin = weight.shape[:2]
+        first_seg = cin if first_seg is None else first_seg
+        self.cin_pad = lib.sr_conv3x3_cin_pad16(cin, first_seg, seg)
+        if self.cin_pad <= 0:
+            raise ValueError(f'cin={cin} is not first_seg={first_seg} + k*seg={seg}')
+        self.cout, self.src_channels = cout, self.cin_pad
+        dev = weight.device
+        self.w = torch.empty((cout + 31) // 32 * 32 * self.cin_pad * 9, dtype=torch.bfloat16, device=dev)
+        self.b = None
+        if bias is not None:
+            bias = bias.detach().contiguous().float()
+            self.b = torch.empty(lib.sr_conv3x3_packed_bias_floats(cout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_conv3x3_pack_bf16(weight.data_ptr(), bias.data_ptr() if self.b is not None else None, cout,
+                                                cin, first_seg, seg, self.w.data_ptr(),
+                                                self.b.data_ptr() if self.b is not None else None, _stream(dev)),
+                       'sr_conv3x3_pack_bf16')
+
+
+def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
+                 beta2=0.0, out_nchw=None):
+    """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16."""
+    lib = _lib.load()
+    assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
+    H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
+    d = _lib.ConvDesc()
+    d.in_, d.in_img_stride, d.cin_pad, d.in_h, d.in_w = src.ptr, src.img_stride, pc.src_channels, src.h, src.w
+    d.upsample = int(upsample)
+    d.wpacked, d.bpacked, d.cout = pc.w.data_ptr(), (pc.b.data_ptr() if pc.b is not None else None), pc.cout
+    if out_nchw is not None:
+        assert out_nchw.is_contiguous() and out_nchw.dtype == torch.float32 and out_nchw.shape == (src.n, pc.cout, H, W)
+        d.out, d.out_img_stride, d.out_nchw = out_nchw.data_ptr(), pc.cout * H * W, 1
+        ret = out_nchw
+    else:
+        if out is None:
+            out = CB16.zeros(src.n, pc.cout, H, W, src.device)
+        assert (out.n, out.h, out.w) == (src.n, H, W) and out.channels >= (pc.cout + 15) // 16 * 16
+        d.out, d.out_img_stride, d.out_nchw = out.ptr, out.img_stride, 0
+        ret = out
+    d.n, d.act_slope, d.alpha = src.n, act_slope, alpha
+    if res1 is not None:
+        d.res1, d.res1_img_stride, d.beta1 = res1.ptr, res1.img_stride, beta1
+    if res2 is not None:
+        d.res2, d.res2_img_stride, d.beta2 = res2.ptr, res2.img_stride, beta2
+    with torch.cuda.device(src.device):
+        _lib.check(lib.sr_conv3x3_bf16(C.byref(d), _stream(src.device)), 'sr_conv3x3_bf16')
+    return ret

@@ -293,6 +293,25 @@ int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad
                             const float* dy, int n, int h, int w, float* const* host_dparams, float* dx,
                             void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 
+/* ------------------------------------------------- bf16 inference (extension) ---- */
+/* The reference has no reduced precision; BASELINE configs 3-4 name bf16.  Activations are CB16:
+ * __bf16 feat[N][C/16][H][W][16] (32-byte pixels again), weights bf16 MFMA images, bias and accumulation fp32
+ * (v_mfma_f32_32x32x16_bf16).  sr_conv3x3_bf16 takes the same descriptor (pointers to bf16 data passed through the
+ * float* fields, *_img_stride in elements of the tensor's dtype, cin_pad a multiple of 16; accumulate/mask unsupported). */
+int sr_nchw_to_cb16_bf16(const float* src, void* dst, int N, int C, int H, int W, int unshuffle, int dst_cblocks,
+                         int64_t dst_img_stride, void* stream);
+int sr_cb16_to_nchw_f32(const void* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W, void* stream);
+int sr_conv3x3_cin_pad16(int cin, int first_seg, int seg);
+int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg, void* wpacked,
+                         float* bpacked, void* stream);
+int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream);
+size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg);
+size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream);
+/* y (fp32 NCHW) = RRDBNet.forward(x fp32 NCHW) computed in bf16. */
+int sr_rrdbnet_forward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h, int w,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------ measurement ---- */
 
 /* Opt-in per-launch timing used by bench.py's roofline line: between sr_profile_start and
