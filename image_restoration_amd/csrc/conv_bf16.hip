@@ -37,6 +37,7 @@ struct ConvParamsH {
   int in_h, in_w, H, W, tiles_x, tiles_y;
   int src_shift;    // 1: nearest x2 upsample on the fly
   float slope, alpha, beta1, beta2;
+  long long* dbg;  // development: per-workgroup phase clocks
 };
 
 __device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
@@ -44,14 +45,14 @@ __device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int COT, int PT, bool NCHW_OUT>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
+template <int COT, int PT, int NW, bool NCHW_OUT>
+__global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TH = 4 * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+  constexpr int TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
   constexpr int NXU = XBYTES / 1024, NWU = 9 * COT;
   constexpr int WBYTES = NWU * 1024, STAGE = XBYTES + WBYTES;
-  constexpr int NXR = (NXU + 3) / 4, NWR = (NWU + 3) / 4;
+  constexpr int NXR = (NXU + NW - 1) / NW, NWR = (NWU + NW - 1) / NW;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
   int xoff[NXR];  // byte offset inside a block plane; -1 = zero padding
 #pragma unroll
   for (int r = 0; r < NXR; ++r) {
-    const int u = r * 4 + wave;
+    const int u = r * NW + wave;
     const int q = u * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
@@ -91,13 +92,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
     const char* plane = in_n + (size_t)cb * plane_b;
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
-      const int u = r * 4 + wave;
+      const int u = r * NW + wave;
       if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : (const void*)g_zero_line_h, xs + u * 1024);
     }
     const char* wsrc = wg + (size_t)cb * WBYTES + lane * 16;
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
-      const int u = r * 4 + wave;
+      const int u = r * NW + wave;
       if (u < NWU) glds16h(wsrc + u * 1024, ws + u * 1024);
     }
   };
@@ -117,34 +118,63 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
     const char* xs = smem + buf * STAGE + xlane;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      // the PT+2 tile rows of this column offset serve all three dy: 3*(PT+2) + 9*COT reads per chunk, not 9*(PT+COT)
+      bf16x8 bx[PT + 2], a[3][COT];
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int tap = dy * 3 + dx;
-        bf16x8 a[COT], b[PT];
+      for (int r = 0; r < PT + 2; ++r) bx[r] = *(const bf16x8*)(xs + (r * XROW + dx) * 32);
 #pragma unroll
-        for (int c = 0; c < COT; ++c) a[c] = *(const bf16x8*)(ws + (tap * COT + c) * 1024);
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int r = 0; r < PT; ++r) b[r] = *(const bf16x8*)(xs + ((r + dy) * XROW + dx) * 32);
+        for (int c = 0; c < COT; ++c) a[dy][c] = *(const bf16x8*)(ws + ((dy * 3 + dx) * COT + c) * 1024);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int c = 0; c < COT; ++c)
 #pragma unroll
-          for (int r = 0; r < PT; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], b[r], acc[c][r], 0, 0, 0);
-      }
+          for (int r = 0; r < PT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][c], bx[r + dy], acc[c][r], 0, 0, 0);
+    }
   };
 
   const int nchunk = p.cin_blocks;
+  long long tk[6] = {0, 0, 0, 0, 0, 0};
+  if (p.dbg) tk[0] = __builtin_readcyclecounter();
   stage(0, 0);
   __syncthreads();
+  if (p.dbg) tk[1] = __builtin_readcyclecounter();
   for (int c = 0; c < nchunk; ++c) {
+    long long t0 = 0, t1 = 0;
+    if (p.dbg) t0 = __builtin_readcyclecounter();
     if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
     compute(c & 1);
+    if (p.dbg) t1 = __builtin_readcyclecounter();
     __syncthreads();
+    if (p.dbg) {
+      tk[2] += t1 - t0;
+      tk[3] += __builtin_readcyclecounter() - t1;
+    }
   }
+  if (p.dbg) tk[4] = __builtin_readcyclecounter();
 
-  // epilogue: bias, LeakyReLU, residual scale-adds in fp32; bf16x4 (8-byte) stores into CB16, or fp32 NCHW
+  // epilogue: bias, LeakyReLU, residual scale-adds in fp32.  A lane holds 4 consecutive couts per register quad and its
+  // partner lane (same pixel, other half h) the next 4, so 8-byte accesses would touch half of every 32-byte pixel:
+  // v_permlane32_swap exchanges quads between the two lane halves so that every lane loads/stores 16 B = 8 consecutive
+  // channels and a wave instruction covers 1 KB of contiguous memory (full 128-byte lines).
   const int x = x0 + j;
   const long long HW = (long long)p.H * p.W;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto swap_halves = [](u32x4& t) {  // t[0..1].upper-lanes <-> t[2..3].lower-lanes
+    auto r0 = __builtin_amdgcn_permlane32_swap(t[0], t[2], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(t[1], t[3], false, false);
+    t = u32x4{r0[0], r1[0], r0[1], r1[1]};
+  };
+  auto bf2f = [](unsigned w, int hi) { return __builtin_bit_cast(float, hi ? (w & 0xffff0000u) : (w << 16)); };
+  auto f2bf2 = [](float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+  };
 #pragma unroll
   for (int r = 0; r < PT; ++r) {
     const int y = y0 + wave * PT + r;
@@ -152,55 +182,76 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvParamsH p) {
     const long long pixoff = (long long)y * p.W + x;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
+      if constexpr (NCHW_OUT) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co0 = (cog * COT + c) * 32 + g * 8 + h * 4;  // first of this lane's 4 couts
-        const int cb = co0 >> 4;
-        if (cb >= p.cout_blocks) continue;
-        f32x4 v;
+        for (int g = 0; g < 4; ++g) {
+          const int co0 = (cog * COT + c) * 32 + g * 8 + h * 4;  // first of this lane's 4 couts
+          if ((co0 >> 4) >= p.cout_blocks) continue;
+          f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[c][r][g * 4 + e];
-        if (p.bias) v += *(const f32x4*)(p.bias + co0);
+          for (int e = 0; e < 4; ++e) v[e] = acc[c][r][g * 4 + e];
+          if (p.bias) v += *(const f32x4*)(p.bias + co0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-        v *= p.alpha;
-        const long long off = ((cb * HW + pixoff) * 16 + (co0 & 15)) * 2;  // bytes
-        if (p.res1) {
-          const bf16x4 rv = *(const bf16x4*)(p.res1 + (long long)n * p.res1_nb + off);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.beta1 * (float)rv[e];
-        }
-        if (p.res2) {
-          const bf16x4 rv = *(const bf16x4*)(p.res2 + (long long)n * p.res2_nb + off);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.beta2 * (float)rv[e];
-        }
-        if constexpr (NCHW_OUT) {
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+          v *= p.alpha;
           float* on = (float*)(p.out + (long long)n * p.out_nb) + pixoff;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (co0 + e < p.cout) on[(co0 + e) * HW] = v[e];
-        } else {
-          bf16x4 o;
+        }
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-          *(bf16x4*)(p.out + (long long)n * p.out_nb + off) = o;
+        for (int m = 0; m < 2; ++m) {  // the two 16-channel blocks of this 32-cout tile
+          const int cb = (cog * COT + c) * 2 + m;
+          if (cb >= p.cout_blocks) continue;
+          const long long off = ((cb * HW + pixoff) * 16 + h * 8) * 2;  // bytes: this lane's 8 channels of the pixel
+          f32x4 v[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int g = 2 * m + q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = acc[c][r][g * 4 + e];
+            if (p.bias) v[q] += *(const f32x4*)(p.bias + (cog * COT + c) * 32 + g * 8 + h * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = v[q][e] > 0.f ? v[q][e] : v[q][e] * p.slope;
+            v[q] *= p.alpha;
+          }
+          auto add_res = [&](const char* res, long long nb, float beta) {
+            u32x4 rr = *(const u32x4*)(res + (long long)n * nb + off);  // channels 8h..8h+7
+            swap_halves(rr);  // -> rr[0..1] = quad 2m, rr[2..3] = quad 2m+1 of this lane
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[q][e] += beta * bf2f(rr[q * 2 + (e >> 1)], e & 1);
+          };
+          if (p.res1) add_res(p.res1, p.res1_nb, p.beta1);
+          if (p.res2) add_res(p.res2, p.res2_nb, p.beta2);
+          u32x4 o = {f2bf2(v[0][0], v[0][1]), f2bf2(v[0][2], v[0][3]), f2bf2(v[1][0], v[1][1]), f2bf2(v[1][2], v[1][3])};
+          swap_halves(o);
+          *(u32x4*)(p.out + (long long)n * p.out_nb + off) = o;
         }
       }
     }
   }
+  if (p.dbg && lane == 0) {
+    tk[5] = __builtin_readcyclecounter();
+    long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+    o[0] = tk[0]; o[1] = tk[1] - tk[0]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tk[4] - tk[0]; o[5] = tk[5] - tk[4];
+    o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
 }
 
-template <int COT, int PT>
+template <int COT, int PT, int NW>
 constexpr int conv_bf16_lds() {
-  return 2 * ((((4 * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
+  return 2 * ((((NW * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
 }
 
-template <int COT, int PT, bool NCHW_OUT>
+template <int COT, int PT, int NW, bool NCHW_OUT>
 int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
-  constexpr int lds = conv_bf16_lds<COT, PT>();
+  constexpr int lds = conv_bf16_lds<COT, PT, NW>();
+  static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
   static bool attr_set = false;
-  auto kern = conv_bf16_kernel<COT, PT, NCHW_OUT>;
+  auto kern = conv_bf16_kernel<COT, PT, NW, NCHW_OUT>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       sr::set_error("sr_conv3x3_bf16: hipFuncSetAttribute(%d) failed", lds);
@@ -209,11 +260,11 @@ int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv
     attr_set = true;
   }
   p.tiles_x = sr::cdiv(p.W, 32);
-  p.tiles_y = sr::cdiv(p.H, 4 * PT);
+  p.tiles_y = sr::cdiv(p.H, NW * PT);
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = 16 + (COT - 1) * 2 + (PT == 4 ? 1 : 0) + (NCHW_OUT ? 4 : 0);
+    r.kernel_id = 16 + (COT - 1) * 2 + (PT == 4 ? 1 : 0) + (NCHW_OUT ? 4 : 0) + (NW == 8 ? 8 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
@@ -225,13 +276,19 @@ int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv
                      (d->res2 ? px * r.cout : 0));
     sr::prof_begin(stream, r);
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * n, groups), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * n, groups), dim3(NW * 64), lds, stream, p);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("conv_bf16 launch");
   return SR_OK;
 }
 
+long long* g_phase_clocks = nullptr;
+
 }  // namespace
+
+// Development aid (tools/bf16_phase.py; not part of the ABI in include/sr_hip.h): when set, every wave of the next
+// launches writes its prologue / compute / barrier-wait / epilogue cycle counts to buf[(workgroup*NW + wave)*8 ..].
+extern "C" void sr_dev_conv_bf16_phase_clocks(void* buf) { g_phase_clocks = (long long*)buf; }
 
 // d->in / out / res*: CB16 bf16 tensors (out: NCHW fp32 when out_nchw); *_img_stride in ELEMENTS of the tensor's dtype;
 // cin_pad multiple of 16; wpacked from sr_conv3x3_pack_bf16 (passed through the float* field); bpacked fp32.
@@ -267,16 +324,24 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   p.alpha = d->alpha;
   p.beta1 = d->beta1;
   p.beta2 = d->beta2;
+  p.dbg = g_phase_clocks;
   SR_CHECK_ARG((long long)p.H * p.W * 32 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) < (1ll << 31),
                "sr_conv3x3_bf16: image too large for 32-bit plane offsets");
   const int cp = (d->cout + 31) / 32 * 32;
   const int gc = (cp % 64 == 0) ? 64 : 32;
   const int groups = cp / gc;
+  // 8-wave workgroups (32x32-pixel tiles, two waves per SIMD: one wave's LDS latency and barrier wait hide behind the
+  // other's MFMAs, and a chunk of MFMA work is as long as the refill latency) whenever the image has whole 32-row tiles.
+  const bool w8 = p.H % 32 == 0;
   if (d->out_nchw) {
     if (p.out_nb == 0) p.out_nb = (long long)d->cout * p.H * p.W * 4;
-    return gc == 64 ? launch_h<2, 2, true>(p, d->n, groups, stream, d) : launch_h<1, 2, true>(p, d->n, groups, stream, d);
+    if (gc == 64) return w8 ? launch_h<2, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, true>(p, d->n, groups, stream, d);
+    return w8 ? launch_h<1, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, true>(p, d->n, groups, stream, d);
   }
-  const bool big = (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, 16) * d->n * groups >= 512 && p.H % 16 == 0;
-  if (gc == 64) return big ? launch_h<2, 4, false>(p, d->n, groups, stream, d) : launch_h<2, 2, false>(p, d->n, groups, stream, d);
-  return big ? launch_h<1, 4, false>(p, d->n, groups, stream, d) : launch_h<1, 2, false>(p, d->n, groups, stream, d);
+  if (gc == 64) {
+    if (w8) return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);
+    return p.H % 16 == 0 ? launch_h<2, 4, 4, false>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, false>(p, d->n, groups, stream, d);
+  }
+  if (w8) return launch_h<1, 4, 8, false>(p, d->n, groups, stream, d);
+  return p.H % 16 == 0 ? launch_h<1, 4, 4, false>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, false>(p, d->n, groups, stream, d);
 }

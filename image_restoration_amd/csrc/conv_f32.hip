@@ -619,11 +619,14 @@ extern "C" const char* sr_kernel_name(int id) {
   if (id >= 8 && id < 13) return wnames[id - 8];
   if (id == 13) return "conv_f32_kernelILi1ELi4ELi3ELb0E";
   if (id == 14) return "conv_fewcout_f32_kernelILi3E";
-  if (id >= 16 && id < 24) {  // conv_bf16.hip: 16 + (COT-1)*2 + (PT==4) + 4*NCHW_OUT
-    static const char* hnames[8] = {"conv_bf16_kernelILi1ELi2ELb0E", "conv_bf16_kernelILi1ELi4ELb0E",
-                                    "conv_bf16_kernelILi2ELi2ELb0E", "conv_bf16_kernelILi2ELi4ELb0E",
-                                    "conv_bf16_kernelILi1ELi2ELb1E", "conv_bf16_kernelILi1ELi4ELb1E",
-                                    "conv_bf16_kernelILi2ELi2ELb1E", "conv_bf16_kernelILi2ELi4ELb1E"};
+  if (id >= 16 && id < 32) {  // conv_bf16.hip: 16 + (COT-1)*2 + (PT==4) + 4*NCHW_OUT + 8*(NW==8)
+    static const char* hnames[16] = {
+        "conv_bf16_kernelILi1ELi2ELi4ELb0E", "conv_bf16_kernelILi1ELi4ELi4ELb0E", "conv_bf16_kernelILi2ELi2ELi4ELb0E",
+        "conv_bf16_kernelILi2ELi4ELi4ELb0E", "conv_bf16_kernelILi1ELi2ELi4ELb1E", "conv_bf16_kernelILi1ELi4ELi4ELb1E",
+        "conv_bf16_kernelILi2ELi2ELi4ELb1E", "conv_bf16_kernelILi2ELi4ELi4ELb1E", "conv_bf16_kernelILi1ELi2ELi8ELb0E",
+        "conv_bf16_kernelILi1ELi4ELi8ELb0E", "conv_bf16_kernelILi2ELi2ELi8ELb0E", "conv_bf16_kernelILi2ELi4ELi8ELb0E",
+        "conv_bf16_kernelILi1ELi2ELi8ELb1E", "conv_bf16_kernelILi1ELi4ELi8ELb1E", "conv_bf16_kernelILi2ELi2ELi8ELb1E",
+        "conv_bf16_kernelILi2ELi4ELi8ELb1E"};
     return hnames[id - 16];
   }
   return (id >= 0 && id < 8) ? names[id] : "";
