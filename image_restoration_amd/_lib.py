@@ -115,16 +115,33 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_nchw_to_cb16_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
                                        C.c_void_p]),
-    'sr_cb16_to_nchw_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_cb16_to_nchw_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
     'sr_conv3x3_cin_pad16': (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    'sr_conv3x3_pack_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                       C.c_void_p]),
+    'sr_conv3x3_packed_weight_elems_bf16': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'sr_conv3x3_pack_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     'sr_conv3x3_bf16': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    'sr_conv3x3_wgrad_slab_bytes_bf16': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'sr_conv3x3_wgrad_bf16': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    'sr_upsample2x_bwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_cb16_axpby_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
     'sr_rrdbnet_packed_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_workspace_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_pack_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     'sr_rrdbnet_forward_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_rrdbnet_saved_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_backward_workspace_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_rrdbnet_packed_dgrad_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
+    'sr_rrdbnet_pack_dgrad_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'sr_rrdbnet_forward_train_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_rrdbnet_backward_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_int, C.c_void_p]),
     'sr_set_forward_groups': (C.c_int, [C.c_int]),
     'sr_rrdbnet_saved_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_backward_workspace_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),

@@ -84,8 +84,8 @@ class RRDBNet(nn.Module):
         self._packed_h_key = None
 
     def set_compute_dtype(self, dtype):
-        """'fp32' (reference numerics, default) or 'bf16' (inference only: bf16 activations/weights on
-        v_mfma_f32_32x32x16_bf16 with fp32 accumulation; training always runs fp32)."""
+        """'fp32' (reference numerics, default) or 'bf16' (bf16 activations, activation gradients and weight images on
+        v_mfma_f32_32x32x16_bf16; fp32 master weights, accumulation, parameter gradients and optimiser)."""
         if dtype not in ('fp32', 'bf16'):
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
         self.compute_dtype = dtype
@@ -120,19 +120,19 @@ class RRDBNet(nn.Module):
         self._packed_key = key
         return self._packed
 
-    def _ensure_packed_dgrad(self, lib, cfg, stream):
-        """Transposed/flipped weight images for the data-gradient convs, cached per parameter version."""
+    def _ensure_packed_dgrad(self, lib, cfg, stream, bf16=False):
+        """Transposed/flipped weight images for the data-gradient convs, cached per parameter version (and dtype)."""
         params = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in params[0::2])
+        key = (bf16,) + tuple((p.data_ptr(), p._version) for p in params[0::2])
         if getattr(self, '_packed_dg', None) is not None and key == self._packed_dg_key:
             return self._packed_dg
         dev = params[0].device
-        nbytes = lib.sr_rrdbnet_packed_dgrad_bytes(C.byref(cfg))
+        nbytes = (lib.sr_rrdbnet_packed_dgrad_bytes_bf16 if bf16 else lib.sr_rrdbnet_packed_dgrad_bytes)(C.byref(cfg))
         if getattr(self, '_packed_dg', None) is None or self._packed_dg.numel() != nbytes or self._packed_dg.device != dev:
             self._packed_dg = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         ptrs = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
-        _lib.check(lib.sr_rrdbnet_pack_dgrad_f32(C.byref(cfg), ptrs, self._packed_dg.data_ptr(), stream),
-                   'sr_rrdbnet_pack_dgrad_f32')
+        pack = lib.sr_rrdbnet_pack_dgrad_bf16 if bf16 else lib.sr_rrdbnet_pack_dgrad_f32
+        _lib.check(pack(C.byref(cfg), ptrs, self._packed_dg.data_ptr(), stream), 'sr_rrdbnet_pack_dgrad')
         self._packed_dg_key = key
         return self._packed_dg
 
@@ -178,20 +178,26 @@ class RRDBNet(nn.Module):
             stream = torch.cuda.current_stream().cuda_stream
             return self._launch(lib, cfg, x, n, h, w, stream)
 
-    def _launch_bf16(self, lib, cfg, x, n, h, w, stream):
+    def _ensure_packed_bf16(self, lib, cfg, stream):
+        """bf16 MFMA weight images, rounded from the fp32 master parameters; cached per parameter version."""
         params = self._param_list()
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._packed_h is None or key != self._packed_h_key:
+            dev = params[0].device
             nb = lib.sr_rrdbnet_packed_bytes_bf16(C.byref(cfg))
-            if self._packed_h is None or self._packed_h.numel() != nb or self._packed_h.device != x.device:
-                self._packed_h = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            if self._packed_h is None or self._packed_h.numel() != nb or self._packed_h.device != dev:
+                self._packed_h = torch.empty(nb, dtype=torch.uint8, device=dev)
             for p in params:
-                if p.device != x.device or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise _lib.SrHipError('RRDBNet parameters must be contiguous fp32 on the input device')
+                if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.SrHipError('RRDBNet parameters must be contiguous fp32 on one HIP device')
             ptrs = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
             _lib.check(lib.sr_rrdbnet_pack_bf16(C.byref(cfg), ptrs, self._packed_h.data_ptr(), stream),
                        'sr_rrdbnet_pack_bf16')
             self._packed_h_key = key
+        return self._packed_h
+
+    def _launch_bf16(self, lib, cfg, x, n, h, w, stream):
+        self._ensure_packed_bf16(lib, cfg, stream)
         nbytes = lib.sr_rrdbnet_workspace_bytes_bf16(C.byref(cfg), n, h, w)
         if nbytes == 0:
             raise _lib.SrHipError(f'sr_rrdbnet_workspace_bytes_bf16 returned 0 for input {h}x{w}')

@@ -2,6 +2,8 @@
 
 forward  -> sr_rrdbnet_forward_train_f32 (keeps the activations in a device workspace)
 backward -> sr_rrdbnet_backward_f32 (data + weight gradients of all 351 convs as HIP launches)
+With ``net.set_compute_dtype('bf16')`` the *_bf16 twins run instead (bf16 activations and activation gradients,
+fp32 master weights, fp32 parameter gradients); x, y and every tensor autograd sees stay fp32.
 
 This is what stands where the reference relies on autograd through nn.Conv2d / LeakyReLU / cat /
 interpolate (rrdbnet_arch.py:105-119 under esrgan_model.py:18,47).  Parameter gradients are
@@ -28,8 +30,9 @@ class _RRDBNetFunction(torch.autograd.Function):
         dev = x.device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
-            packed = net._ensure_packed(lib, cfg, stream)
-            nbytes = lib.sr_rrdbnet_saved_bytes(C.byref(cfg), n, h, w)
+            bf16 = net.compute_dtype == 'bf16'
+            packed = net._ensure_packed_bf16(lib, cfg, stream) if bf16 else net._ensure_packed(lib, cfg, stream)
+            nbytes = (lib.sr_rrdbnet_saved_bytes_bf16 if bf16 else lib.sr_rrdbnet_saved_bytes)(C.byref(cfg), n, h, w)
             if nbytes == 0:
                 u = {4: 1, 2: 2, 1: 4}[cfg.scale]
                 assert h % u == 0 and w % u == 0, f'input {h}x{w} is not divisible by the pixel_unshuffle factor {u}'
@@ -37,10 +40,10 @@ class _RRDBNetFunction(torch.autograd.Function):
             saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             up = {4: 4, 2: 2, 1: 1}[cfg.scale]
             y = torch.empty((n, net.num_out_ch, h * up, w * up), dtype=torch.float32, device=dev)
-            _lib.check(lib.sr_rrdbnet_forward_train_f32(C.byref(cfg), packed.data_ptr(), x.data_ptr(), y.data_ptr(), n,
-                                                        h, w, saved.data_ptr(), nbytes, stream),
-                       'sr_rrdbnet_forward_train_f32')
-        ctx.net, ctx.cfg, ctx.saved, ctx.shape = net, cfg, saved, (n, h, w)
+            fwd = lib.sr_rrdbnet_forward_train_bf16 if bf16 else lib.sr_rrdbnet_forward_train_f32
+            _lib.check(fwd(C.byref(cfg), packed.data_ptr(), x.data_ptr(), y.data_ptr(), n, h, w, saved.data_ptr(), nbytes,
+                           stream), 'sr_rrdbnet_forward_train_' + ('bf16' if bf16 else 'f32'))
+        ctx.net, ctx.cfg, ctx.saved, ctx.shape, ctx.bf16 = net, cfg, saved, (n, h, w), bf16
         ctx.x_shape = tuple(x.shape)
         ctx.param_versions = tuple(p._version for p in params)
         ctx.params = params
@@ -49,7 +52,7 @@ class _RRDBNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        net, cfg, (n, h, w) = ctx.net, ctx.cfg, ctx.shape
+        net, cfg, (n, h, w), bf16 = ctx.net, ctx.cfg, ctx.shape, ctx.bf16
         params = ctx.params
         dy = dy.contiguous().float()
         dev = dy.device
@@ -58,8 +61,9 @@ class _RRDBNetFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             # data-gradient weight images (transposed / flipped), cached per parameter version
-            packed_dg = net._ensure_packed_dgrad(lib, cfg, stream)
-            wbytes = lib.sr_rrdbnet_backward_workspace_bytes(C.byref(cfg), n, h, w)
+            packed_dg = net._ensure_packed_dgrad(lib, cfg, stream, bf16)
+            wbytes = (lib.sr_rrdbnet_backward_workspace_bytes_bf16 if bf16 else
+                      lib.sr_rrdbnet_backward_workspace_bytes)(C.byref(cfg), n, h, w)
             ws = net._bwd_workspace(wbytes, dev)
             sink = getattr(net, '_grad_sink', None)
             if sink is not None and any(need_p):
@@ -79,10 +83,10 @@ class _RRDBNetFunction(torch.autograd.Function):
                         raise _lib.SrHipError('bias.requires_grad without weight.requires_grad is not supported')
                 accumulate = 0
             dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
-            _lib.check(lib.sr_rrdbnet_backward_f32(C.byref(cfg), packed_dg.data_ptr(), ctx.saved.data_ptr(),
-                                                   ctx.saved.numel(), dy.data_ptr(), n, h, w, ptrs,
-                                                   dx.data_ptr() if dx is not None else None, ws.data_ptr(), wbytes,
-                                                   accumulate, stream), 'sr_rrdbnet_backward_f32')
+            bwd = lib.sr_rrdbnet_backward_bf16 if bf16 else lib.sr_rrdbnet_backward_f32
+            _lib.check(bwd(C.byref(cfg), packed_dg.data_ptr(), ctx.saved.data_ptr(), ctx.saved.numel(), dy.data_ptr(), n, h, w,
+                           ptrs, dx.data_ptr() if dx is not None else None, ws.data_ptr(), wbytes, accumulate, stream),
+                       'sr_rrdbnet_backward_' + ('bf16' if bf16 else 'f32'))
         ctx.saved = None
         return (None, dx) + tuple(grads)
 

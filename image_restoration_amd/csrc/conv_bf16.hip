@@ -30,13 +30,15 @@ struct ConvParamsH {
   char* out;          // CB16 bf16, or NCHW fp32 when NCHW_OUT
   const char* res1;
   const char* res2;
-  long long in_nb, out_nb, res1_nb, res2_nb;  // image strides in BYTES
+  const char* mask;  // CB16 forward activation whose sign gates the output (LeakyReLU backward), first mask_cbn blocks
+  long long in_nb, out_nb, res1_nb, res2_nb, mask_nb;  // image strides in BYTES
   int cin_blocks;   // Cin / 16
   int cout_blocks;  // valid 16-channel blocks of the destination (ceil(cout/16))
   int cout;
   int in_h, in_w, H, W, tiles_x, tiles_y;
   int src_shift;    // 1: nearest x2 upsample on the fly
-  float slope, alpha, beta1, beta2;
+  int mask_cbn;
+  float slope, alpha, beta1, beta2, mask_slope;
   long long* dbg;  // development: per-workgroup phase clocks
 };
 
@@ -226,6 +228,15 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
           };
           if (p.res1) add_res(p.res1, p.res1_nb, p.beta1);
           if (p.res2) add_res(p.res2, p.res2_nb, p.beta2);
+          if (p.mask && cb < p.mask_cbn) {
+            u32x4 mm = *(const u32x4*)(p.mask + (long long)n * p.mask_nb + off);
+            swap_halves(mm);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (!(bf2f(mm[q * 2 + (e >> 1)], e & 1) > 0.f)) v[q][e] *= p.mask_slope;
+          }
           u32x4 o = {f2bf2(v[0][0], v[0][1]), f2bf2(v[0][2], v[0][3]), f2bf2(v[1][0], v[1][1]), f2bf2(v[1][2], v[1][3])};
           swap_halves(o);
           *(u32x4*)(p.out + (long long)n * p.out_nb + off) = o;
@@ -297,9 +308,10 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   SR_CHECK_ARG(d && d->in && d->wpacked && d->out, "sr_conv3x3_bf16: null argument");
   SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 16 == 0, "sr_conv3x3_bf16: cin_pad=%d must be a multiple of 16", d->cin_pad);
   SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_bf16: bad shape");
-  SR_CHECK_ARG(!d->accumulate && !d->mask_src && d->res_cbn == 0, "sr_conv3x3_bf16: accumulate/mask are fp32-path options");
+  SR_CHECK_ARG(!d->accumulate && d->res_cbn == 0 && d->mask_cb0 == 0 && !(d->mask_src && d->out_nchw),
+               "sr_conv3x3_bf16: accumulate / res_cbn / mask_cb0 are fp32-path options");
   SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 | (uintptr_t)d->res2 |
-                (uintptr_t)d->bpacked) % 16 == 0,
+                (uintptr_t)d->bpacked | (uintptr_t)d->mask_src) % 16 == 0,
                "sr_conv3x3_bf16: pointers must be 16-byte aligned");
   ConvParamsH p = {};
   p.in = (const char*)d->in;
@@ -312,6 +324,10 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   p.out_nb = d->out_img_stride * (d->out_nchw ? 4 : 2);
   p.res1_nb = d->res1_img_stride * 2;
   p.res2_nb = d->res2_img_stride * 2;
+  p.mask = (const char*)d->mask_src;
+  p.mask_nb = d->mask_img_stride * 2;
+  p.mask_cbn = d->mask_cbn;
+  p.mask_slope = d->mask_slope;
   p.cin_blocks = d->cin_pad / 16;
   p.cout_blocks = (d->cout + 15) / 16;
   p.cout = d->cout;

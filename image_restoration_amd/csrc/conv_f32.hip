@@ -629,5 +629,10 @@ extern "C" const char* sr_kernel_name(int id) {
         "conv_bf16_kernelILi2ELi4ELi8ELb1E"};
     return hnames[id - 16];
   }
+  if (id >= 32 && id < 38) {  // wgrad_bf16.hip
+    static const char* gnames[6] = {"wgrad_bf16_kernelILi1ELi1ELi8E", "wgrad_bf16_kernelILi1ELi2ELi4E", "wgrad_bf16_kernelILi1ELi4ELi2E",
+                                    "wgrad_bf16_kernelILi2ELi1ELi4E", "wgrad_bf16_kernelILi2ELi2ELi2E", "wgrad_bf16_kernelILi2ELi4ELi1E"};
+    return gnames[id - 32];
+  }
   return (id >= 0 && id < 8) ? names[id] : "";
 }

@@ -368,117 +368,3 @@ int rdb_pack_dgrad_step(const float* const w[5], int nf, int gc, int s, float sc
   return SR_OK;
 }
 }  // namespace sr
-
-// ---- bf16 (CB16) layout and weight images ---------------------------------------------------------------------
-namespace {
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-// NCHW fp32 -> CB16 bf16 (pixel_unshuffle fused like nchw_to_cb8): one thread per destination half pixel-block (8 ch)
-__global__ void nchw_to_cb16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int C, int H, int W, int u,
-                                    int cblocks, long long dst_ns, long long total) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int half = (int)(i & 1);
-  long long r = i >> 1;
-  const int HW = H * W;
-  const int pix = (int)(r % HW);
-  r /= HW;
-  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
-  const int y = pix / W, x = pix - y * W;
-  const int Cu = C * u * u, SH = H * u, SW = W * u;
-  bf16x8_t v;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cb * 16 + half * 8 + e;
-    float val = 0.f;
-    if (c < Cu) {
-      const int ix = c % u, iy = (c / u) % u, cs = c / (u * u);
-      val = src[((long long)(n * C + cs) * SH + (y * u + iy)) * SW + (x * u + ix)];
-    }
-    v[e] = (__bf16)val;
-  }
-  *(bf16x8_t*)(dst + n * dst_ns + ((long long)cb * HW + pix) * 16 + half * 8) = v;
-}
-
-__global__ void cb16_to_nchw_kernel(const __bf16* __restrict__ src, long long src_ns, float* __restrict__ dst, int C, int H,
-                                    int W, long long total) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int HW = H * W;
-  const int pix = (int)(i % HW);
-  long long r = i / HW;
-  const int c = (int)(r % C), n = (int)(r / C);
-  dst[i] = (float)src[n * src_ns + ((long long)(c >> 4) * HW + pix) * 16 + (c & 15)];
-}
-
-// OIHW fp32 -> bf16 image wp[g][cb16][tap][gc][16]; concat segments start on multiples of 16 channels
-__global__ void pack_w_bf16_kernel(const float* __restrict__ w, int cout, int cin, int first_seg, int seg, int cin_pad,
-                                   __bf16* __restrict__ wp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cout * cin * 9) return;
-  const int tap = i % 9, ci = (i / 9) % cin, co = i / (9 * cin);
-  int pos = ci;
-  if (ci >= first_seg) {
-    const int r = ci - first_seg;
-    pos = (first_seg + 15) / 16 * 16 + (r / seg) * ((seg + 15) / 16 * 16) + r % seg;
-  }
-  const int gc = (((cout + 31) / 32 * 32) % 64 == 0) ? 64 : 32;
-  const int cbs = cin_pad / 16;
-  const int g = co / gc, col = co % gc;
-  wp[((((long long)g * cbs + (pos >> 4)) * 9 + tap) * gc + col) * 16 + (pos & 15)] = (__bf16)w[i];
-}
-}  // namespace
-
-extern "C" int sr_nchw_to_cb16_bf16(const float* src, void* dst, int N, int C, int H, int W, int unshuffle, int dst_cblocks,
-                                    int64_t dst_img_stride, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "sr_nchw_to_cb16_bf16: bad argument");
-  SR_CHECK_ARG(unshuffle == 1 || unshuffle == 2 || unshuffle == 4, "sr_nchw_to_cb16_bf16: unshuffle must be 1, 2 or 4");
-  SR_CHECK_ARG(dst_cblocks * 16 >= C * unshuffle * unshuffle, "sr_nchw_to_cb16_bf16: dst_cblocks too small");
-  const long long total = (long long)N * dst_cblocks * H * W * 2;
-  hipLaunchKernelGGL(nchw_to_cb16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, (__bf16*)dst, C, H,
-                     W, unshuffle, dst_cblocks, (long long)dst_img_stride, total);
-  SR_CHECK_LAUNCH("nchw_to_cb16");
-  return SR_OK;
-}
-
-extern "C" int sr_cb16_to_nchw_f32(const void* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W,
-                                   void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "sr_cb16_to_nchw_f32: bad argument");
-  const long long total = (long long)N * C * H * W;
-  hipLaunchKernelGGL(cb16_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const __bf16*)src,
-                     (long long)src_img_stride, dst, C, H, W, total);
-  SR_CHECK_LAUNCH("cb16_to_nchw");
-  return SR_OK;
-}
-
-extern "C" int sr_conv3x3_cin_pad16(int cin, int first_seg, int seg) {
-  if (cin <= 0 || first_seg <= 0 || first_seg > cin) return SR_EINVAL;
-  if (first_seg == cin) return (cin + 15) / 16 * 16;
-  if (seg <= 0 || (cin - first_seg) % seg != 0) return SR_EINVAL;
-  return (first_seg + 15) / 16 * 16 + ((cin - first_seg) / seg) * ((seg + 15) / 16 * 16);
-}
-
-extern "C" int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg,
-                                    void* wpacked, float* bpacked, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(weight && wpacked && cout > 0 && cin > 0, "sr_conv3x3_pack_bf16: bad argument");
-  const int cin_pad = sr_conv3x3_cin_pad16(cin, first_seg, seg);
-  SR_CHECK_ARG(cin_pad > 0, "sr_conv3x3_pack_bf16: cin=%d is not first_seg=%d + k*seg=%d", cin, first_seg, seg);
-  const size_t elems = (size_t)((cout + 31) / 32 * 32) * cin_pad * 9;
-  if (hipMemsetAsync(wpacked, 0, elems * 2, stream) != hipSuccess) {
-    sr::set_error("sr_conv3x3_pack_bf16: memset failed");
-    return SR_ELAUNCH;
-  }
-  const int total = cout * cin * 9;
-  hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, cout, cin, first_seg,
-                     seg > 0 ? seg : 1, cin_pad, (__bf16*)wpacked);
-  SR_CHECK_LAUNCH("pack_w_bf16");
-  if (bpacked) {
-    const int cp = (int)sr_conv3x3_packed_bias_floats(cout);
-    hipLaunchKernelGGL(pack_b_kernel, dim3((cp + 255) / 256), dim3(256), 0, stream, bias, cout, cp, bpacked);
-    SR_CHECK_LAUNCH("pack_b");
-  }
-  return SR_OK;
-}

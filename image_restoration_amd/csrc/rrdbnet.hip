@@ -634,196 +634,3 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
   }
   return SR_OK;
 }
-
-// ===================================================================== bf16 inference (build extension)
-// Same launch sequence as forward_body on CB16 bf16 activations and bf16 weight images (fp32 bias, fp32 accumulation,
-// fp32 NCHW output).  Packed blob: per conv [bf16 weight image | fp32 bias], offsets in bytes.
-extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream);
-extern "C" int sr_conv3x3_cin_pad16(int cin, int first_seg, int seg);
-extern "C" int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg,
-                                    void* wpacked, float* bpacked, void* stream);
-extern "C" int sr_nchw_to_cb16_bf16(const float* src, void* dst, int N, int C, int H, int W, int unshuffle, int dst_cblocks,
-                                    int64_t dst_img_stride, void* stream);
-
-namespace {
-int r16(int v) { return (v + 15) / 16 * 16; }
-
-struct ConvPlanH {
-  int cout, cin, first_seg, seg, cin_pad;
-  size_t w_off, b_off;  // byte offsets
-};
-struct NetPlanH {
-  int nfp, gcp, cin0, cin0_pad, unshuffle;
-  std::vector<ConvPlanH> convs;
-  size_t packed_bytes;
-};
-
-bool make_plan_h(const sr_rrdbnet_cfg* c, NetPlanH* P) {
-  NetPlan base;
-  if (!make_plan(c, &base)) return false;
-  P->unshuffle = base.unshuffle;
-  P->cin0 = base.cin0;
-  P->cin0_pad = r16(base.cin0);
-  P->nfp = r16(c->num_feat);
-  P->gcp = r16(c->num_grow_ch);
-  size_t off = 0;
-  for (const ConvPlan& b : base.convs) {
-    ConvPlanH cp;
-    cp.cout = b.cout;
-    cp.cin = b.cin;
-    cp.first_seg = b.first_seg;
-    cp.seg = b.seg;
-    cp.cin_pad = sr_conv3x3_cin_pad16(b.cin, b.first_seg, b.seg);
-    cp.w_off = off;
-    off += sr::align_up((size_t)((b.cout + 31) / 32 * 32) * cp.cin_pad * 9 * 2, 256);
-    cp.b_off = off;
-    off += sr::align_up(sr_conv3x3_packed_bias_floats(b.cout) * 4, 256);
-    P->convs.push_back(cp);
-  }
-  P->packed_bytes = off;
-  return true;
-}
-
-struct FwdSpaceH {
-  char *xin, *feat0, *cat[4], *trunk, *up1, *up2, *hr;
-  size_t bytes;
-};
-FwdSpaceH carve_h(const NetPlanH& P, int n, int h, int w, char* base) {
-  FwdSpaceH W;
-  size_t off = 0;
-  const size_t hw = (size_t)h * w;
-  auto take = [&](size_t elems) {
-    char* p = base + off;
-    off += sr::align_up(elems * 2, 256);
-    return p;
-  };
-  const int ctot = P.nfp + 4 * P.gcp;
-  W.xin = take((size_t)n * P.cin0_pad * hw);
-  W.feat0 = take((size_t)n * P.nfp * hw);
-  for (int i = 0; i < 4; ++i) W.cat[i] = take((size_t)n * ctot * hw);
-  W.trunk = take((size_t)n * P.nfp * hw);
-  W.up1 = take((size_t)n * P.nfp * hw * 4);
-  W.up2 = take((size_t)n * P.nfp * hw * 16);
-  W.hr = take((size_t)n * P.nfp * hw * 16);
-  W.bytes = off;
-  return W;
-}
-}  // namespace
-
-extern "C" size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg) {
-  NetPlanH P;
-  return make_plan_h(cfg, &P) ? P.packed_bytes : 0;
-}
-
-extern "C" size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
-  NetPlanH P;
-  if (!make_plan_h(cfg, &P) || n <= 0 || h <= 0 || w <= 0 || h % P.unshuffle || w % P.unshuffle) return 0;
-  return carve_h(P, n, h / P.unshuffle, w / P.unshuffle, nullptr).bytes;
-}
-
-extern "C" int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream) {
-  NetPlanH P;
-  SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_pack_bf16: bad config");
-  SR_CHECK_ARG(host_params && packed, "sr_rrdbnet_pack_bf16: null argument");
-  for (size_t i = 0; i < P.convs.size(); ++i) {
-    const ConvPlanH& cp = P.convs[i];
-    SR_CHECK_ARG(host_params[2 * i] && host_params[2 * i + 1], "sr_rrdbnet_pack_bf16: null parameter %zu", i);
-    int rc = sr_conv3x3_pack_bf16(host_params[2 * i], host_params[2 * i + 1], cp.cout, cp.cin, cp.first_seg, cp.seg,
-                                  (char*)packed + cp.w_off, (float*)((char*)packed + cp.b_off), stream);
-    if (rc) return rc;
-  }
-  return SR_OK;
-}
-
-extern "C" int sr_rrdbnet_forward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n,
-                                       int h_in, int w_in, void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  NetPlanH P;
-  SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_forward_bf16: bad config");
-  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "sr_rrdbnet_forward_bf16: bad argument");
-  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "sr_rrdbnet_forward_bf16: input not divisible by %d",
-               P.unshuffle);
-  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "sr_rrdbnet_forward_bf16: workspace must be 256-byte aligned");
-  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
-  const FwdSpaceH W = carve_h(P, n, h, w, (char*)workspace);
-  if (W.bytes > workspace_bytes) {
-    sr::set_error("sr_rrdbnet_forward_bf16: workspace %zu B < required %zu B", workspace_bytes, W.bytes);
-    return SR_ENOSPACE;
-  }
-  const long long hw = (long long)h * w;
-  const int ctot = P.nfp + 4 * P.gcp;
-  const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;  // bf16 elements
-  int rc = sr_nchw_to_cb16_bf16(x, W.xin, n, cfg->num_in_ch, h, w, P.unshuffle, P.cin0_pad / 16, (long long)P.cin0_pad * hw,
-                                stream);
-  if (rc) return rc;
-  size_t ci = 0;
-  auto conv = [&](const char* in, long long in_ns, int ih, int iw, int ups, void* out, long long out_ns, float slope,
-                  float alpha, const char* r1, long long r1_ns, float b1, const char* r2, long long r2_ns, float b2,
-                  int out_nchw) -> int {
-    const ConvPlanH& cp = P.convs[ci++];
-    sr_conv3x3_desc d = {};
-    d.in = (const float*)in;
-    d.in_img_stride = in_ns;
-    d.cin_pad = cp.cin_pad;
-    d.cin_real = cp.cin;
-    d.in_h = ih;
-    d.in_w = iw;
-    d.upsample = ups;
-    d.wpacked = (const float*)((const char*)packed + cp.w_off);
-    d.bpacked = (const float*)((const char*)packed + cp.b_off);
-    d.cout = cp.cout;
-    d.out = (float*)out;
-    d.out_img_stride = out_ns;
-    d.out_nchw = out_nchw;
-    d.n = n;
-    d.act_slope = slope;
-    d.alpha = alpha;
-    d.res1 = (const float*)r1;
-    d.res1_img_stride = r1_ns;
-    d.beta1 = b1;
-    d.res2 = (const float*)r2;
-    d.res2_img_stride = r2_ns;
-    d.beta2 = b2;
-    return sr_conv3x3_bf16(&d, stream);
-  };
-  auto slice = [&](char* buf, int ch) { return buf + (long long)ch * hw * 2; };
-  const bool blocks = cfg->num_block > 0;
-  char* first_dst = blocks ? W.cat[0] : W.feat0;
-  const long long first_ns = blocks ? cat_ns : feat_ns;
-  rc = conv(W.xin, (long long)P.cin0_pad * hw, h, w, 0, first_dst, first_ns, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
-  if (rc) return rc;
-  if (blocks) {
-    if (hipMemcpy2DAsync(W.feat0, feat_ns * 2, W.cat[0], cat_ns * 2, feat_ns * 2, n, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
-      sr::set_error("sr_rrdbnet_forward_bf16: feat0 copy failed");
-      return SR_ELAUNCH;
-    }
-  }
-  for (int b = 0; b < cfg->num_block; ++b) {
-    const char* x_rrdb = W.cat[(3 * b) & 3];
-    for (int r = 0; r < 3; ++r) {
-      char* buf = W.cat[(3 * b + r) & 3];
-      char* nxt = W.cat[(3 * b + r + 1) & 3];
-      for (int k = 1; k <= 4; ++k) {
-        rc = conv(buf, cat_ns, h, w, 0, slice(buf, P.nfp + (k - 1) * P.gcp), cat_ns, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
-        if (rc) return rc;
-      }
-      if (r < 2)
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f, 0);
-      else
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f, 0);
-      if (rc) return rc;
-    }
-  }
-  const char* body_out = blocks ? W.cat[(3 * cfg->num_block) & 3] : W.feat0;
-  const long long body_ns = blocks ? cat_ns : feat_ns;
-  rc = conv(body_out, body_ns, h, w, 0, W.trunk, feat_ns, 1.f, 1.f, W.feat0, feat_ns, 1.f, nullptr, 0, 0.f, 0);
-  if (rc) return rc;
-  rc = conv(W.trunk, feat_ns, h, w, 1, W.up1, feat_ns * 4, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
-  if (rc) return rc;
-  rc = conv(W.up1, feat_ns * 4, 2 * h, 2 * w, 1, W.up2, feat_ns * 16, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
-  if (rc) return rc;
-  rc = conv(W.up2, feat_ns * 16, 4 * h, 4 * w, 0, W.hr, feat_ns * 16, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
-  if (rc) return rc;
-  return conv(W.hr, feat_ns * 16, 4 * h, 4 * w, 0, y, (long long)cfg->num_out_ch * hw * 16, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0,
-              0.f, 1);
-}

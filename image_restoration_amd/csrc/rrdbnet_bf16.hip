@@ -1,0 +1,482 @@
+// RRDBNet drivers of the bf16 path (extension; the reference is fp32-only, SURVEY.md §0 D5, BASELINE configs 3-4):
+// the launch sequences of rrdbnet.hip — RRDBNet.forward (rrdbnet_arch.py:105-119), the same forward under autograd and
+// autograd's backward through it (esrgan_model.py:18,47) — on CB16 bf16 activations / activation gradients with bf16
+// weight images, fp32 bias, fp32 accumulation and fp32 parameter gradients.  x, y, dy, dx are fp32 NCHW like the fp32
+// entry points, so the Python side (archs/rrdbnet_autograd.py) only switches symbols.
+#include <vector>
+
+#include "sr_internal.h"
+
+namespace {
+int r16(int v) { return (v + 15) / 16 * 16; }
+
+struct ConvPlanH {
+  int cout, cin, first_seg, seg, cin_pad;
+  size_t w_off, b_off;  // byte offsets in the packed (forward) blob
+  size_t dg_off;        // byte offset in the packed data-gradient blob (non-RDB convs)
+};
+struct NetPlanH {
+  int nfp, gcp, cin0, cin0_pad, unshuffle;
+  std::vector<ConvPlanH> convs;  // state_dict order
+  std::vector<size_t> rdb_dg;    // [rdb][step s = 0..4] byte offsets of the transposed-dense-block images
+  size_t packed_bytes, dgrad_bytes;
+};
+
+bool make_plan_h(const sr_rrdbnet_cfg* c, NetPlanH* P) {
+  if (!c || c->num_in_ch <= 0 || c->num_out_ch <= 0 || c->num_feat <= 0 || c->num_block < 0 || c->num_grow_ch <= 0)
+    return false;
+  if (c->scale != 4 && c->scale != 2 && c->scale != 1) return false;
+  P->unshuffle = c->scale == 4 ? 1 : (c->scale == 2 ? 2 : 4);  // rrdbnet_arch.py:90-93
+  P->cin0 = c->num_in_ch * P->unshuffle * P->unshuffle;
+  P->cin0_pad = r16(P->cin0);
+  P->nfp = r16(c->num_feat);
+  P->gcp = r16(c->num_grow_ch);
+  size_t off = 0, dg = 0;
+  auto add = [&](int cout, int cin, int first_seg, int seg) {
+    ConvPlanH cp;
+    cp.cout = cout;
+    cp.cin = cin;
+    cp.first_seg = first_seg;
+    cp.seg = seg;
+    cp.cin_pad = sr_conv3x3_cin_pad16(cin, first_seg, seg);
+    cp.w_off = off;
+    off += sr::align_up(sr_conv3x3_packed_weight_elems_bf16(cout, cin, first_seg, seg, 0) * 2, 256);
+    cp.b_off = off;
+    off += sr::align_up(sr_conv3x3_packed_bias_floats(cout) * 4, 256);
+    cp.dg_off = dg;
+    dg += sr::align_up(sr_conv3x3_packed_weight_elems_bf16(cout, cin, first_seg, seg, 1) * 2, 256);
+    P->convs.push_back(cp);
+  };
+  const int nf = c->num_feat, gc = c->num_grow_ch;
+  add(nf, P->cin0, P->cin0, 0);  // conv_first
+  for (int b = 0; b < c->num_block; ++b)
+    for (int r = 0; r < 3; ++r) {
+      const size_t dg_before = dg;
+      for (int k = 1; k <= 4; ++k) add(gc, nf + (k - 1) * gc, nf, gc);
+      add(nf, nf + 4 * gc, nf, gc);
+      dg = dg_before;  // per-conv images replaced by the five step images of the transposed dense block
+      for (int s = 0; s < 5; ++s) {
+        P->rdb_dg.push_back(dg);
+        dg += sr::align_up(sr::rdb_dgrad_step_elems16(nf, gc, s) * 2, 256);
+      }
+    }
+  add(nf, nf, nf, 0);             // conv_body
+  add(nf, nf, nf, 0);             // conv_up1
+  add(nf, nf, nf, 0);             // conv_up2
+  add(nf, nf, nf, 0);             // conv_hr
+  add(c->num_out_ch, nf, nf, 0);  // conv_last
+  P->packed_bytes = off;
+  P->dgrad_bytes = dg;
+  return true;
+}
+
+struct CarverH {
+  char* base;
+  size_t off = 0;
+  __bf16* take(size_t elems) {
+    __bf16* p = (__bf16*)(base + off);
+    off += sr::align_up(elems * 2, 256);
+    return p;
+  }
+};
+
+struct FwdSpaceH {
+  __bf16 *xin, *feat0, *trunk, *up1, *up2, *hr;
+  std::vector<__bf16*> cat;
+  size_t bytes;
+};
+// train = false: 4 rotating concat buffers; train = true: one per RDB + 1 (they are the saved activations)
+FwdSpaceH carve_fwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, int w, char* base, bool train) {
+  FwdSpaceH W;
+  CarverH cv{base};
+  const size_t hw = (size_t)h * w;
+  const int ctot = P.nfp + 4 * P.gcp;
+  W.xin = cv.take((size_t)n * P.cin0_pad * hw);
+  W.feat0 = cv.take((size_t)n * P.nfp * hw);
+  const int ncat = train ? 3 * c->num_block + 1 : 4;
+  for (int i = 0; i < ncat; ++i) W.cat.push_back(cv.take((size_t)n * ctot * hw));
+  W.trunk = cv.take((size_t)n * P.nfp * hw);
+  W.up1 = cv.take((size_t)n * P.nfp * hw * 4);
+  W.up2 = cv.take((size_t)n * P.nfp * hw * 16);
+  W.hr = cv.take((size_t)n * P.nfp * hw * 16);
+  W.bytes = cv.off;
+  return W;
+}
+
+struct BwdSpaceH {
+  __bf16 *dyl, *a16, *b16, *a4, *b4, *dtrunk, *g[4], *dxin;
+  void* slab;
+  size_t slab_bytes, bytes;
+};
+BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, int w, char* base) {
+  BwdSpaceH B;
+  CarverH cv{base};
+  const size_t hw = (size_t)h * w;
+  const int ctot = P.nfp + 4 * P.gcp;
+  B.dyl = cv.take((size_t)n * r16(c->num_out_ch) * hw * 16);
+  B.a16 = cv.take((size_t)n * P.nfp * hw * 16);
+  B.b16 = cv.take((size_t)n * P.nfp * hw * 16);
+  B.a4 = cv.take((size_t)n * P.nfp * hw * 4);
+  B.b4 = cv.take((size_t)n * P.nfp * hw * 4);
+  B.dtrunk = cv.take((size_t)n * P.nfp * hw);
+  for (int i = 0; i < 4; ++i) B.g[i] = cv.take((size_t)n * ctot * hw);
+  B.dxin = cv.take((size_t)n * P.cin0_pad * hw);
+  B.slab_bytes = sr_conv3x3_wgrad_slab_bytes_bf16(n, 4 * h, 4 * w);
+  B.slab = cv.take(B.slab_bytes / 2);
+  B.bytes = cv.off;
+  return B;
+}
+
+int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h_in, int w_in,
+              void* workspace, size_t workspace_bytes, hipStream_t stream, bool train, const char* who) {
+  NetPlanH P;
+  SR_CHECK_ARG(make_plan_h(cfg, &P), "%s: bad config", who);
+  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "%s: bad argument", who);
+  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "%s: input not divisible by %d", who, P.unshuffle);
+  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "%s: workspace must be 256-byte aligned", who);
+  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  const FwdSpaceH W = carve_fwd_h(cfg, P, n, h, w, (char*)workspace, train);
+  if (W.bytes > workspace_bytes) {
+    sr::set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, W.bytes);
+    return SR_ENOSPACE;
+  }
+  const long long hw = (long long)h * w;
+  const int ctot = P.nfp + 4 * P.gcp;
+  const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;  // bf16 elements
+  int rc = sr_nchw_to_cb16_bf16(x, W.xin, n, cfg->num_in_ch, h, w, P.unshuffle, P.cin0_pad / 16, (long long)P.cin0_pad * hw,
+                                stream);
+  if (rc) return rc;
+  size_t ci = 0;
+  auto conv = [&](const __bf16* in, long long in_ns, int ih, int iw, int ups, void* out, long long out_ns, float slope,
+                  float alpha, const __bf16* r1, long long r1_ns, float b1, const __bf16* r2, long long r2_ns, float b2,
+                  int out_nchw) -> int {
+    const ConvPlanH& cp = P.convs[ci++];
+    sr_conv3x3_desc d = {};
+    d.in = (const float*)in;
+    d.in_img_stride = in_ns;
+    d.cin_pad = cp.cin_pad;
+    d.cin_real = cp.cin;
+    d.in_h = ih;
+    d.in_w = iw;
+    d.upsample = ups;
+    d.wpacked = (const float*)((const char*)packed + cp.w_off);
+    d.bpacked = (const float*)((const char*)packed + cp.b_off);
+    d.cout = cp.cout;
+    d.out = (float*)out;
+    d.out_img_stride = out_ns;
+    d.out_nchw = out_nchw;
+    d.n = n;
+    d.act_slope = slope;
+    d.alpha = alpha;
+    d.res1 = (const float*)r1;
+    d.res1_img_stride = r1_ns;
+    d.beta1 = b1;
+    d.res2 = (const float*)r2;
+    d.res2_img_stride = r2_ns;
+    d.beta2 = b2;
+    return sr_conv3x3_bf16(&d, stream);
+  };
+  const bool blocks = cfg->num_block > 0;
+  const int ncat = (int)W.cat.size();
+  auto catbuf = [&](int q) { return W.cat[train ? q : (q & 3)]; };
+  (void)ncat;
+  __bf16* first_dst = blocks ? catbuf(0) : W.feat0;
+  const long long first_ns = blocks ? cat_ns : feat_ns;
+  rc = conv(W.xin, (long long)P.cin0_pad * hw, h, w, 0, first_dst, first_ns, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
+  if (rc) return rc;
+  if (blocks) {  // keep conv_first's output for the long skip (:114); the concat buffers rotate / are overwritten
+    if (hipMemcpy2DAsync(W.feat0, feat_ns * 2, catbuf(0), cat_ns * 2, feat_ns * 2, n, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+      sr::set_error("%s: feat0 copy failed", who);
+      return SR_ELAUNCH;
+    }
+  }
+  for (int b = 0; b < cfg->num_block; ++b) {
+    const __bf16* x_rrdb = catbuf(3 * b);
+    for (int r = 0; r < 3; ++r) {
+      __bf16* buf = catbuf(3 * b + r);
+      __bf16* nxt = catbuf(3 * b + r + 1);
+      for (int k = 1; k <= 4; ++k) {
+        rc = conv(buf, cat_ns, h, w, 0, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, cat_ns, 0.2f, 1.f, nullptr, 0, 0.f,
+                  nullptr, 0, 0.f, 0);
+        if (rc) return rc;
+      }
+      if (r < 2)
+        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f, 0);
+      else
+        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f, 0);
+      if (rc) return rc;
+    }
+  }
+  const __bf16* body_out = blocks ? catbuf(3 * cfg->num_block) : W.feat0;
+  const long long body_ns = blocks ? cat_ns : feat_ns;
+  rc = conv(body_out, body_ns, h, w, 0, W.trunk, feat_ns, 1.f, 1.f, W.feat0, feat_ns, 1.f, nullptr, 0, 0.f, 0);
+  if (rc) return rc;
+  rc = conv(W.trunk, feat_ns, h, w, 1, W.up1, feat_ns * 4, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
+  if (rc) return rc;
+  rc = conv(W.up1, feat_ns * 4, 2 * h, 2 * w, 1, W.up2, feat_ns * 16, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
+  if (rc) return rc;
+  rc = conv(W.up2, feat_ns * 16, 4 * h, 4 * w, 0, W.hr, feat_ns * 16, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0);
+  if (rc) return rc;
+  return conv(W.hr, feat_ns * 16, 4 * h, 4 * w, 0, y, (long long)cfg->num_out_ch * hw * 16, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0,
+              0.f, 1);
+}
+}  // namespace
+
+extern "C" size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg) {
+  NetPlanH P;
+  return make_plan_h(cfg, &P) ? P.packed_bytes : 0;
+}
+
+extern "C" size_t sr_rrdbnet_packed_dgrad_bytes_bf16(const sr_rrdbnet_cfg* cfg) {
+  NetPlanH P;
+  return make_plan_h(cfg, &P) ? P.dgrad_bytes : 0;
+}
+
+static size_t fwd_bytes_h(const sr_rrdbnet_cfg* cfg, int n, int h, int w, bool train) {
+  NetPlanH P;
+  if (!make_plan_h(cfg, &P) || n <= 0 || h <= 0 || w <= 0 || h % P.unshuffle || w % P.unshuffle) return 0;
+  return carve_fwd_h(cfg, P, n, h / P.unshuffle, w / P.unshuffle, nullptr, train).bytes;
+}
+extern "C" size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  return fwd_bytes_h(cfg, n, h, w, false);
+}
+extern "C" size_t sr_rrdbnet_saved_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  return fwd_bytes_h(cfg, n, h, w, true);
+}
+extern "C" size_t sr_rrdbnet_backward_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
+  NetPlanH P;
+  if (!make_plan_h(cfg, &P) || n <= 0 || h <= 0 || w <= 0 || h % P.unshuffle || w % P.unshuffle) return 0;
+  return carve_bwd_h(cfg, P, n, h / P.unshuffle, w / P.unshuffle, nullptr).bytes;
+}
+
+extern "C" int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream) {
+  NetPlanH P;
+  SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_pack_bf16: bad config");
+  SR_CHECK_ARG(host_params && packed, "sr_rrdbnet_pack_bf16: null argument");
+  for (size_t i = 0; i < P.convs.size(); ++i) {
+    const ConvPlanH& cp = P.convs[i];
+    SR_CHECK_ARG(host_params[2 * i] && host_params[2 * i + 1], "sr_rrdbnet_pack_bf16: null parameter %zu", i);
+    int rc = sr_conv3x3_pack_bf16(host_params[2 * i], host_params[2 * i + 1], cp.cout, cp.cin, cp.first_seg, cp.seg, 0,
+                                  (char*)packed + cp.w_off, (float*)((char*)packed + cp.b_off), stream);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_pack_dgrad_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed_dgrad,
+                                          void* stream) {
+  NetPlanH P;
+  SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_pack_dgrad_bf16: bad config");
+  SR_CHECK_ARG(host_params && packed_dgrad, "sr_rrdbnet_pack_dgrad_bf16: null argument");
+  const int n_rdb = 3 * cfg->num_block;
+  for (size_t i = 0; i < P.convs.size(); ++i) {
+    const ConvPlanH& cp = P.convs[i];
+    SR_CHECK_ARG(host_params[2 * i], "sr_rrdbnet_pack_dgrad_bf16: null parameter %zu", i);
+    if (i >= 1 && i < 1 + 5 * (size_t)n_rdb) continue;  // dense-block convs: packed per step below
+    int rc = sr_conv3x3_pack_bf16(host_params[2 * i], nullptr, cp.cout, cp.cin, cp.first_seg, cp.seg, 1,
+                                  (char*)packed_dgrad + cp.dg_off, nullptr, stream);
+    if (rc) return rc;
+  }
+  for (int q = 0; q < n_rdb; ++q) {
+    const float* w[5];
+    for (int k = 0; k < 5; ++k) w[k] = host_params[2 * (1 + 5 * q + k)];
+    const float scale5 = (q % 3 == 2) ? 0.04f : 0.2f;  // x5*0.2 (+ the RRDB's *0.2 for rdb3), rrdbnet_arch.py:39,63
+    for (int s = 0; s < 5; ++s) {
+      int rc = sr::rdb_pack_dgrad_step_bf16(w, cfg->num_feat, cfg->num_grow_ch, s, scale5,
+                                            (char*)packed_dgrad + P.rdb_dg[q * 5 + s], (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  }
+  return SR_OK;
+}
+
+extern "C" int sr_rrdbnet_forward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h,
+                                       int w, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_h(cfg, packed, x, y, n, h, w, workspace, workspace_bytes, (hipStream_t)stream, false, "sr_rrdbnet_forward_bf16");
+}
+
+extern "C" int sr_rrdbnet_forward_train_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n,
+                                             int h, int w, void* saved, size_t saved_bytes, void* stream) {
+  return forward_h(cfg, packed, x, y, n, h, w, saved, saved_bytes, (hipStream_t)stream, true, "sr_rrdbnet_forward_train_bf16");
+}
+
+extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed_dgrad, const void* saved, size_t saved_bytes,
+                                        const float* dy, int n, int h_in, int w_in, float* const* host_dparams, float* dx,
+                                        void* workspace, size_t workspace_bytes, int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NetPlanH P;
+  SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_backward_bf16: bad config");
+  SR_CHECK_ARG(packed_dgrad && saved && dy && host_dparams && workspace && n > 0, "sr_rrdbnet_backward_bf16: bad argument");
+  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "sr_rrdbnet_backward_bf16: bad spatial size");
+  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)saved % 256 == 0,
+               "sr_rrdbnet_backward_bf16: workspaces must be 256-byte aligned");
+  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  const FwdSpaceH S = carve_fwd_h(cfg, P, n, h, w, (char*)saved, true);
+  const BwdSpaceH B = carve_bwd_h(cfg, P, n, h, w, (char*)workspace);
+  if (S.bytes > saved_bytes || B.bytes > workspace_bytes) {
+    sr::set_error("sr_rrdbnet_backward_bf16: saved %zu/%zu B, workspace %zu/%zu B", saved_bytes, S.bytes, workspace_bytes,
+                  B.bytes);
+    return SR_ENOSPACE;
+  }
+  const long long hw = (long long)h * w;
+  const int nfb = P.nfp / 16, gcb = P.gcp / 16;
+  const int ctot = P.nfp + 4 * P.gcp;
+  const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;
+  const int nconv = (int)P.convs.size();
+  int rc;
+
+  // data gradient of conv `ci`: out = dgrad(in) [LeakyReLU-backward mask of the activation that fed the conv]
+  auto dgrad = [&](int ci, const __bf16* in, long long in_ns, int oh, int ow, __bf16* out, long long out_ns,
+                   const __bf16* mask, long long mask_ns, int mask_cbn) -> int {
+    const ConvPlanH& cp = P.convs[ci];
+    sr_conv3x3_desc d = {};
+    d.in = (const float*)in;
+    d.in_img_stride = in_ns;
+    d.cin_pad = r16(cp.cout);
+    d.cin_real = cp.cout;
+    d.in_h = oh;
+    d.in_w = ow;
+    d.wpacked = (const float*)((const char*)packed_dgrad + cp.dg_off);
+    d.cout = cp.cin_pad;
+    d.out = (float*)out;
+    d.out_img_stride = out_ns;
+    d.n = n;
+    d.act_slope = 1.f;
+    d.alpha = 1.f;
+    d.mask_src = (const float*)mask;
+    d.mask_img_stride = mask_ns;
+    d.mask_cbn = mask_cbn;
+    d.mask_slope = 0.2f;
+    return sr_conv3x3_bf16(&d, stream);
+  };
+  auto wgrad = [&](int ci, const __bf16* xsrc, long long x_ns, int ih, int iw, int ups, const __bf16* dyp, long long dy_ns,
+                   float scale) -> int {
+    const ConvPlanH& cp = P.convs[ci];
+    float* dwp = host_dparams[2 * ci];
+    float* dbp = host_dparams[2 * ci + 1];
+    if (!dwp) return SR_OK;  // parameter does not need a gradient
+    sr_conv3x3_wgrad_desc d = {};
+    d.x = (const float*)xsrc;
+    d.x_img_stride = x_ns;
+    d.cin_pad = cp.cin_pad;
+    d.in_h = ih;
+    d.in_w = iw;
+    d.upsample = ups;
+    d.dy = (const float*)dyp;
+    d.dy_img_stride = dy_ns;
+    d.cout = cp.cout;
+    d.cin = cp.cin;
+    d.first_seg = cp.first_seg;
+    d.seg = cp.seg;
+    d.n = n;
+    d.scale = scale;
+    d.dweight = dwp;
+    d.dbias = dbp;
+    d.accumulate = accumulate;
+    d.slab = B.slab;
+    d.slab_bytes = B.slab_bytes;
+    return sr_conv3x3_wgrad_bf16(&d, stream);
+  };
+
+  const int i_first = 0, i_body = nconv - 5, i_up1 = nconv - 4, i_up2 = nconv - 3, i_hr = nconv - 2, i_last = nconv - 1;
+  const int ocb = r16(cfg->num_out_ch) / 16;
+  const long long ohw = hw * 16, dyl_ns = (long long)ocb * 16 * ohw;
+  rc = sr_nchw_to_cb16_bf16(dy, B.dyl, n, cfg->num_out_ch, 4 * h, 4 * w, 1, ocb, dyl_ns, stream);  // dL/dy (NCHW) -> CB16
+  if (rc) return rc;
+  // conv_last (:118): no activation after it; its input hr = lrelu(conv_hr(..))
+  rc = wgrad(i_last, S.hr, feat_ns * 16, 4 * h, 4 * w, 0, B.dyl, dyl_ns, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_last, B.dyl, dyl_ns, 4 * h, 4 * w, B.a16, feat_ns * 16, S.hr, feat_ns * 16, nfb);  // a16 = dL/d(conv_hr pre-act)
+  if (rc) return rc;
+  rc = wgrad(i_hr, S.up2, feat_ns * 16, 4 * h, 4 * w, 0, B.a16, feat_ns * 16, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_hr, B.a16, feat_ns * 16, 4 * h, 4 * w, B.b16, feat_ns * 16, S.up2, feat_ns * 16, nfb);  // b16 = dL/d(conv_up2 pre-act)
+  if (rc) return rc;
+  // conv_up2 reads up1 through the nearest x2 upsample (:117)
+  rc = wgrad(i_up2, S.up1, feat_ns * 4, 2 * h, 2 * w, 1, B.b16, feat_ns * 16, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16, feat_ns * 16, nullptr, 0, 0);  // a16 = dL/d(upsampled up1)
+  if (rc) return rc;
+  rc = sr_upsample2x_bwd_bf16(B.a16, feat_ns * 16, B.a4, feat_ns * 4, S.up1, feat_ns * 4, 0.2f, n, nfb, 2 * h, 2 * w, stream);
+  if (rc) return rc;  // a4 = dL/d(conv_up1 pre-activation)
+  rc = wgrad(i_up1, S.trunk, feat_ns, h, w, 1, B.a4, feat_ns * 4, 1.f);
+  if (rc) return rc;
+  rc = dgrad(i_up1, B.a4, feat_ns * 4, 2 * h, 2 * w, B.b4, feat_ns * 4, nullptr, 0, 0);
+  if (rc) return rc;
+  rc = sr_upsample2x_bwd_bf16(B.b4, feat_ns * 4, B.dtrunk, feat_ns, nullptr, 0, 0.2f, n, nfb, h, w, stream);
+  if (rc) return rc;  // dtrunk = dL/d(feat + body_feat)
+  // conv_body (:113): input = body output
+  const bool blocks = cfg->num_block > 0;
+  const __bf16* body_out = blocks ? S.cat[3 * cfg->num_block] : S.feat0;
+  const long long body_ns = blocks ? cat_ns : feat_ns;
+  rc = wgrad(i_body, body_out, body_ns, h, w, 0, B.dtrunk, feat_ns, 1.f);
+  if (rc) return rc;
+  int gi = 0;  // G buffer holding the gradient wrt the current block output in its first nfb blocks
+  rc = dgrad(i_body, B.dtrunk, feat_ns, h, w, B.g[gi], cat_ns, nullptr, 0, 0);
+  if (rc) return rc;
+  // body, in reverse: each RDB's data gradient is a transposed dense block over D = [dY5 | dY4 | dY3 | dY2 | dY1]
+  auto step = [&](int q, int sidx, const __bf16* in, int cin_pad, __bf16* out, int cout, const __bf16* r1, float b1,
+                  const __bf16* r2, float b2, const __bf16* mask, int mask_cbn) -> int {
+    sr_conv3x3_desc d = {};
+    d.in = (const float*)in;
+    d.in_img_stride = cat_ns;
+    d.cin_pad = cin_pad;
+    d.cin_real = cin_pad;
+    d.in_h = h;
+    d.in_w = w;
+    d.wpacked = (const float*)((const char*)packed_dgrad + P.rdb_dg[q * 5 + sidx]);
+    d.cout = cout;
+    d.out = (float*)out;
+    d.out_img_stride = cat_ns;
+    d.n = n;
+    d.act_slope = 1.f;
+    d.alpha = 1.f;
+    d.res1 = (const float*)r1;
+    d.res1_img_stride = cat_ns;
+    d.beta1 = b1;
+    d.res2 = (const float*)r2;
+    d.res2_img_stride = cat_ns;
+    d.beta2 = b2;
+    d.mask_src = (const float*)mask;
+    d.mask_img_stride = cat_ns;
+    d.mask_cbn = mask_cbn;
+    d.mask_slope = 0.2f;
+    return sr_conv3x3_bf16(&d, stream);
+  };
+  for (int b = cfg->num_block - 1; b >= 0; --b) {
+    const __bf16* d_rrdb = B.g[gi];  // dL/d(RRDB output)
+    for (int r = 2; r >= 0; --r) {
+      const int q = 3 * b + r;
+      const __bf16* cat = S.cat[q];
+      __bf16* D = B.g[gi];  // D[0:nf] = dL/d(block output)
+      __bf16* Dn = B.g[(gi + 1) & 3];
+      const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
+      rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);  // conv5: dY5 = s5 * D[0:nf]
+      if (rc) return rc;
+      for (int sl = 4; sl >= 1; --sl) {  // dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k
+        __bf16* dys = D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw;
+        rc = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, dys, cfg->num_grow_ch, nullptr, 0.f, nullptr, 0.f,
+                  cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
+        if (rc) return rc;
+        rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, dys, cat_ns, 1.f);
+        if (rc) return rc;
+      }
+      // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
+      rc = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
+      if (rc) return rc;
+      gi = (gi + 1) & 3;
+    }
+  }
+  // dL/d(conv_first output) = gradient through the body + the long skip (:114)
+  rc = sr_cb16_axpby_bf16(B.g[gi], cat_ns, B.dtrunk, feat_ns, 1.f, 1.f, n, nfb, h, w, stream);
+  if (rc) return rc;
+  rc = wgrad(i_first, S.xin, (long long)P.cin0_pad * hw, h, w, 0, B.g[gi], cat_ns, 1.f);
+  if (rc) return rc;
+  if (dx) {
+    rc = dgrad(i_first, B.g[gi], cat_ns, h, w, B.dxin, (long long)P.cin0_pad * hw, nullptr, 0, 0);
+    if (rc) return rc;
+    rc = sr_cb16_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}

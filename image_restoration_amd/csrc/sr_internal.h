@@ -14,6 +14,22 @@ void prof_begin(hipStream_t s, const sr_launch_record& r);
 void prof_end(hipStream_t s);
 size_t rdb_dgrad_step_floats(int nf, int gc, int s);
 int rdb_pack_dgrad_step(const float* const w[5], int nf, int gc, int s, float scale5, float* out, hipStream_t stream);
+size_t rdb_dgrad_step_elems16(int nf, int gc, int s);
+int rdb_pack_dgrad_step_bf16(const float* const w[5], int nf, int gc, int s, float scale5, void* out, hipStream_t stream);
+struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hip
+  const float* slab;
+  const float* bslab;  // null: no bias gradient
+  float* part;
+  float* bpart;
+  long long splits;
+  int P, IT, CT, ntap, ks, kdim, t_mul, dy_off, dx_off, cin_tile0, cout_tile0;
+  int cout, cin, first_seg, seg, seg_pad;
+  float scale;
+  int accumulate;
+  float* dw;
+  float* db;
+};
+int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
 
 #define SR_CHECK_ARG(cond, ...)            \

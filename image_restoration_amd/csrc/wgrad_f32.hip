@@ -281,6 +281,7 @@ struct ReduceParams {
   int kdim, t_mul, dy_off, dx_off;  // kernel position of tap (ty,tx): (ty*t_mul+dy_off, tx*t_mul+dx_off) in a kdim x kdim kernel
   int cin_tile0, cout_tile0;
   int cout, cin, first_seg, seg;  // reference channel counts and concat segmentation
+  int seg_pad;                    // concat segments start on multiples of this many channels (8: CB8, 16: CB16)
   float scale;
   int accumulate;
 };
@@ -298,11 +299,11 @@ __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
     const int pos = (p.cin_tile0 + it) * 32 + (lane & 31);
     // invert the concat position map of sr_conv3x3_pack_f32
     int ci = -1;
-    const int fsp = (p.first_seg + 7) / 8 * 8;
+    const int fsp = (p.first_seg + p.seg_pad - 1) / p.seg_pad * p.seg_pad;
     if (pos < fsp) {
       if (pos < p.first_seg) ci = pos;
     } else if (p.seg > 0) {
-      const int sp = (p.seg + 7) / 8 * 8;
+      const int sp = (p.seg + p.seg_pad - 1) / p.seg_pad * p.seg_pad;
       const int r = pos - fsp, sgi = r / sp, o = r % sp;
       if (o < p.seg) ci = p.first_seg + sgi * p.seg + o;
     }
@@ -382,46 +383,79 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("wgrad3x3_f32 launch");
   // stage 1 partials live behind the bias slab
-  const int e4 = P * NT * 256;
-  int sch = (int)((splits + 63) / 64);
-  if (sch > 64) sch = 64;
-  const int chunk = (int)((splits + sch - 1) / sch);
-  sch = (int)((splits + chunk - 1) / chunk);
-  float* part = (float*)((char*)bslab + d->slab_bytes / 63 / 256 * 256);
-  float* bpart = part + (size_t)64 * 4 * 9 * 1024;  // behind the weight partials
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch), dim3(256), 0, stream, (const float4*)slab,
-                     (float4*)part, e4, (int)splits, chunk, want_bias ? bslab : nullptr, bpart, CT * 32);
-  SR_CHECK_LAUNCH("wgrad_reduce1 launch");
-  ReduceParams rp;
-  rp.part = part;
-  rp.bpart = want_bias ? bpart : nullptr;
-  rp.dw = d->dweight;
-  rp.db = want_bias ? d->dbias : nullptr;
-  rp.sch = sch;
-  rp.splits = (int)splits;
-  rp.P = P;
-  rp.IT = IT;
-  rp.CT = CT;
-  rp.ntap = NT;
-  rp.ks = KT;
-  rp.kdim = tm.kdim;
-  rp.t_mul = tm.t_mul;
-  rp.dy_off = tm.dy_off;
-  rp.dx_off = tm.dx_off;
-  rp.cin_tile0 = cin_tile0;
-  rp.cout_tile0 = cout_tile0;
-  rp.cout = d->cout;
-  rp.cin = d->cin;
-  rp.first_seg = d->first_seg;
-  rp.seg = d->seg;
-  rp.scale = d->scale;
-  rp.accumulate = d->accumulate;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((P * NT * 1024 + 255) / 256), dim3(256), 0, stream, rp);
-  SR_CHECK_LAUNCH("wgrad_reduce2 launch");
-  return SR_OK;
+  sr::WgradReduce rr = {};
+  rr.slab = slab;
+  rr.bslab = want_bias ? bslab : nullptr;
+  rr.part = (float*)((char*)bslab + d->slab_bytes / 63 / 256 * 256);
+  rr.bpart = rr.part + (size_t)64 * 4 * 9 * 1024;  // behind the weight partials
+  rr.splits = splits;
+  rr.P = P;
+  rr.IT = IT;
+  rr.CT = CT;
+  rr.ntap = NT;
+  rr.ks = KT;
+  rr.kdim = tm.kdim;
+  rr.t_mul = tm.t_mul;
+  rr.dy_off = tm.dy_off;
+  rr.dx_off = tm.dx_off;
+  rr.cin_tile0 = cin_tile0;
+  rr.cout_tile0 = cout_tile0;
+  rr.cout = d->cout;
+  rr.cin = d->cin;
+  rr.first_seg = d->first_seg;
+  rr.seg = d->seg;
+  rr.seg_pad = 8;
+  rr.scale = d->scale;
+  rr.accumulate = d->accumulate;
+  rr.dw = d->dweight;
+  rr.db = want_bias ? d->dbias : nullptr;
+  return sr::wgrad_reduce(rr, stream);
 }
 
 }  // namespace
+
+namespace sr {
+// Two-stage deterministic slab reduction + scatter to OIHW, shared by the fp32 and bf16 weight-gradient kernels
+// (both leave fp32 partial tiles in the 32x32 MFMA accumulator layout).  part holds 64 * P*ntap*1024 floats.
+int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
+  const int e4 = r.P * r.ntap * 256;
+  int sch = (int)((r.splits + 63) / 64);
+  if (sch > 64) sch = 64;
+  const int chunk = (int)((r.splits + sch - 1) / sch);
+  sch = (int)((r.splits + chunk - 1) / chunk);
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch), dim3(256), 0, stream, (const float4*)r.slab,
+                     (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32);
+  SR_CHECK_LAUNCH("wgrad_reduce1 launch");
+  ReduceParams rp;
+  rp.part = r.part;
+  rp.bpart = r.bslab ? r.bpart : nullptr;
+  rp.dw = r.dw;
+  rp.db = r.bslab ? r.db : nullptr;
+  rp.sch = sch;
+  rp.splits = (int)r.splits;
+  rp.P = r.P;
+  rp.IT = r.IT;
+  rp.CT = r.CT;
+  rp.ntap = r.ntap;
+  rp.ks = r.ks;
+  rp.kdim = r.kdim;
+  rp.t_mul = r.t_mul;
+  rp.dy_off = r.dy_off;
+  rp.dx_off = r.dx_off;
+  rp.cin_tile0 = r.cin_tile0;
+  rp.cout_tile0 = r.cout_tile0;
+  rp.cout = r.cout;
+  rp.cin = r.cin;
+  rp.first_seg = r.first_seg;
+  rp.seg = r.seg;
+  rp.seg_pad = r.seg_pad;
+  rp.scale = r.scale;
+  rp.accumulate = r.accumulate;
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((r.P * r.ntap * 1024 + 255) / 256), dim3(256), 0, stream, rp);
+  SR_CHECK_LAUNCH("wgrad_reduce2 launch");
+  return SR_OK;
+}
+}  // namespace sr
 
 extern "C" size_t sr_conv3x3_wgrad_slab_bytes(int n, int h, int w) {
   // splits*P = 4 * workgroups for every launch shape; the row-range heuristic of launch_group stops

@@ -344,7 +344,7 @@ def cb16_to_nchw(t, channels):
     lib = _lib.load()
     y = torch.empty((t.n, channels, t.h, t.w), dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
-        _lib.check(lib.sr_cb16_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w,
+        _lib.check(lib.sr_cb16_to_nchw_f32(t.ptr, t.img_stride, y.data_ptr(), t.n, channels, t.h, t.w, 1,
                                            _stream(t.device)), 'sr_cb16_to_nchw_f32')
     return y
 
@@ -352,7 +352,7 @@ def cb16_to_nchw(t, channels):
 class PackedConvBF16:
     """bf16 MFMA weight image (+ fp32 bias) of one 3x3 conv — sr_conv3x3_pack_bf16."""
 
-    def __init__(self, weight, bias=None, first_seg=None, seg=0):
+    def __init__(self, weight, bias=None, first_seg=None, seg=0, mode=0):
         lib = _lib.load()
         _need_cuda(weight, 'PackedConvBF16')
         weight = weight.detach().contiguous().float()
@@ -361,22 +361,26 @@ class PackedConvBF16:
         self.cin_pad = lib.sr_conv3x3_cin_pad16(cin, first_seg, seg)
         if self.cin_pad <= 0:
             raise ValueError(f'cin={cin} is not first_seg={first_seg} + k*seg={seg}')
-        self.cout, self.src_channels = cout, self.cin_pad
+        if mode == 0:
+            self.cout, self.src_channels = cout, self.cin_pad
+        else:  # data-gradient image: consumes dY (cout channels, padded to 16), produces the cin_pad source channels
+            self.cout, self.src_channels = self.cin_pad, (cout + 15) // 16 * 16
         dev = weight.device
-        self.w = torch.empty((cout + 31) // 32 * 32 * self.cin_pad * 9, dtype=torch.bfloat16, device=dev)
+        self.w = torch.empty(lib.sr_conv3x3_packed_weight_elems_bf16(cout, cin, first_seg, seg, mode), dtype=torch.bfloat16,
+                             device=dev)
         self.b = None
-        if bias is not None:
+        if mode == 0 and bias is not None:
             bias = bias.detach().contiguous().float()
             self.b = torch.empty(lib.sr_conv3x3_packed_bias_floats(cout), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.sr_conv3x3_pack_bf16(weight.data_ptr(), bias.data_ptr() if self.b is not None else None, cout,
-                                                cin, first_seg, seg, self.w.data_ptr(),
+                                                cin, first_seg, seg, mode, self.w.data_ptr(),
                                                 self.b.data_ptr() if self.b is not None else None, _stream(dev)),
                        'sr_conv3x3_pack_bf16')
 
 
 def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-                 beta2=0.0, out_nchw=None):
+                 beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2):
     """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16."""
     lib = _lib.load()
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
@@ -400,6 +404,32 @@ def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0,
         d.res1, d.res1_img_stride, d.beta1 = res1.ptr, res1.img_stride, beta1
     if res2 is not None:
         d.res2, d.res2_img_stride, d.beta2 = res2.ptr, res2.img_stride, beta2
+    if mask is not None:
+        d.mask_src, d.mask_img_stride, d.mask_cb0, d.mask_cbn, d.mask_slope = mask.ptr, mask.img_stride, 0, mask.cbn, mask_slope
     with torch.cuda.device(src.device):
         _lib.check(lib.sr_conv3x3_bf16(C.byref(d), _stream(src.device)), 'sr_conv3x3_bf16')
     return ret
+
+
+def conv3x3_wgrad_bf16(src, dy, cout, cin, first_seg=None, seg=0, *, upsample=False, scale=1.0, want_bias=True):
+    """(dweight, dbias) in fp32 from bf16 CB16 source and output gradient — one sr_conv3x3_wgrad_bf16 call."""
+    lib = _lib.load()
+    first_seg = cin if first_seg is None else first_seg
+    cin_pad = lib.sr_conv3x3_cin_pad16(cin, first_seg, seg)
+    assert src.channels == cin_pad, (src.channels, cin_pad)
+    H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
+    assert (dy.n, dy.h, dy.w) == (src.n, H, W) and dy.channels >= (cout + 15) // 16 * 16
+    dev = src.device
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = lib.sr_conv3x3_wgrad_slab_bytes_bf16(src.n, H, W)
+    slab = scratch(dev, nbytes, 'slab16')
+    d = _lib.WgradDesc()
+    d.x, d.x_img_stride, d.cin_pad, d.in_h, d.in_w, d.upsample = src.ptr, src.img_stride, cin_pad, src.h, src.w, int(upsample)
+    d.dy, d.dy_img_stride = dy.ptr, dy.img_stride
+    d.cout, d.cin, d.first_seg, d.seg, d.n, d.scale = cout, cin, first_seg, seg, src.n, scale
+    d.dweight, d.dbias, d.accumulate = dw.data_ptr(), (db.data_ptr() if db is not None else None), 0
+    d.slab, d.slab_bytes = slab.data_ptr(), nbytes
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_conv3x3_wgrad_bf16(C.byref(d), _stream(dev)), 'sr_conv3x3_wgrad_bf16')
+    return dw, db

@@ -293,24 +293,47 @@ int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* packed_dgrad
                             const float* dy, int n, int h, int w, float* const* host_dparams, float* dx,
                             void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 
-/* ------------------------------------------------- bf16 inference (extension) ---- */
-/* The reference has no reduced precision; BASELINE configs 3-4 name bf16.  Activations are CB16:
- * __bf16 feat[N][C/16][H][W][16] (32-byte pixels again), weights bf16 MFMA images, bias and accumulation fp32
- * (v_mfma_f32_32x32x16_bf16).  sr_conv3x3_bf16 takes the same descriptor (pointers to bf16 data passed through the
- * float* fields, *_img_stride in elements of the tensor's dtype, cin_pad a multiple of 16; accumulate/mask unsupported). */
+/* ------------------------------------------------- bf16 path (extension) ---- */
+/* The reference has no reduced precision; BASELINE configs 3-4 name bf16.  Activations and their
+ * gradients are CB16: __bf16 feat[N][C/16][H][W][16] (32-byte pixels again); weights stay fp32 masters
+ * (FlatAdam's arena) and are rounded into bf16 MFMA images per optimiser step; bias, accumulation
+ * (v_mfma_f32_32x32x16_bf16), every epilogue, weight gradients and the optimiser are fp32.
+ * The entry points mirror their *_f32 twins one to one (same reference counterparts); tensors are passed as void*,
+ * descriptors are reused with pointers to bf16 data in the float* fields, *_img_stride in ELEMENTS of the tensor's
+ * dtype, cin_pad a multiple of 16 (sr_conv3x3_cin_pad16).  sr_conv3x3_bf16 does not take accumulate / res_cbn /
+ * mask_cb0; sr_conv3x3_wgrad_bf16 reads bf16 x and dy and writes fp32 dweight / dbias. */
 int sr_nchw_to_cb16_bf16(const float* src, void* dst, int N, int C, int H, int W, int unshuffle, int dst_cblocks,
                          int64_t dst_img_stride, void* stream);
-int sr_cb16_to_nchw_f32(const void* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W, void* stream);
+int sr_cb16_to_nchw_f32(const void* src, int64_t src_img_stride, float* dst, int N, int C, int H, int W, int shuffle,
+                        void* stream);
 int sr_conv3x3_cin_pad16(int cin, int first_seg, int seg);
-int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg, void* wpacked,
-                         float* bpacked, void* stream);
+size_t sr_conv3x3_packed_weight_elems_bf16(int cout, int cin, int first_seg, int seg, int mode);
+int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int cin, int first_seg, int seg, int mode,
+                         void* wpacked, float* bpacked, void* stream);
 int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream);
+size_t sr_conv3x3_wgrad_slab_bytes_bf16(int n, int h, int w);
+int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* stream);
+int sr_upsample2x_bwd_bf16(const void* g, int64_t g_img_stride, void* dst, int64_t dst_img_stride, const void* mask,
+                           int64_t mask_img_stride, float mask_slope, int n, int cblocks, int h, int w, void* stream);
+int sr_cb16_axpby_bf16(void* dst, int64_t dst_img_stride, const void* src, int64_t src_img_stride, float a, float b, int n,
+                       int cblocks, int h, int w, void* stream);
 size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg);
 size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
 int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream);
 /* y (fp32 NCHW) = RRDBNet.forward(x fp32 NCHW) computed in bf16. */
 int sr_rrdbnet_forward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h, int w,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Training twins of sr_rrdbnet_forward_train_f32 / sr_rrdbnet_backward_f32: x, y, dy, dx and the parameter
+ * gradients (host_dparams) are fp32; saved activations and activation gradients are bf16. */
+size_t sr_rrdbnet_saved_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+size_t sr_rrdbnet_backward_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
+size_t sr_rrdbnet_packed_dgrad_bytes_bf16(const sr_rrdbnet_cfg* cfg);
+int sr_rrdbnet_pack_dgrad_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed_dgrad, void* stream);
+int sr_rrdbnet_forward_train_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h,
+                                  int w, void* saved, size_t saved_bytes, void* stream);
+int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed_dgrad, const void* saved, size_t saved_bytes,
+                             const float* dy, int n, int h, int w, float* const* host_dparams, float* dx, void* workspace,
+                             size_t workspace_bytes, int accumulate, void* stream);
 
 /* ------------------------------------------------------------ measurement ---- */
 
