@@ -43,13 +43,13 @@ class RRDB(nn.Module):
 
 @ARCH_REGISTRY.register()
 class RRDBNet(nn.Module):
-    """RRDBNet(num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32).
+    """RRDBNet(num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32[, compute_dtype='fp32']).
 
     forward(x[N, num_in_ch, H, W] fp32 on a HIP device) -> [N, num_out_ch, 4H/s', 4W/s']
     with s' = 1, 2, 4 for scale 4, 2, 1 (pixel_unshuffle at the input, reference :90-93,106-109).
     """
 
-    def __init__(self, num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32):
+    def __init__(self, num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32, compute_dtype='fp32'):
         super().__init__()
         self.scale = scale
         self.num_in_ch, self.num_out_ch = num_in_ch, num_out_ch
@@ -71,9 +71,10 @@ class RRDBNet(nn.Module):
         self._packed_dg_key = None
         self._grad_sink = None    # set by optim.FlatAdam: gradients accumulate straight into its arena
         self._workspaces = {}
-        self.compute_dtype = 'fp32'  # 'bf16' selects the reduced-precision inference kernels (not in the reference)
+        self.compute_dtype = 'fp32'
         self._packed_h = None
         self._packed_h_key = None
+        self.set_compute_dtype(compute_dtype)  # option key beyond the reference's: 'bf16' = reduced-precision kernels
 
     # ------------------------------------------------------------------ HIP plumbing
     def invalidate_packed(self):
