@@ -7,7 +7,20 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
+__device__ __attribute__((aligned(64))) float g_sr_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 namespace sr {
+const void* zero_line() {
+  static void* cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cache[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_sr_zero_line)) == hipSuccess) cache[dev] = ptr;
+  }
+  return cache[dev];
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -21,9 +21,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __attribute__((aligned(64))) float g_zero_line_h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct ConvParamsH {
+  const void* zero;  // sr::zero_line()
   const char* in;     // CB16 bf16
   const char* w;      // packed bf16 image [group][cin/16][tap][32*COT][16]
   const float* bias;  // fp32 [cout pad 32] or null
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
       const int u = r * NW + wave;
-      if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : (const void*)g_zero_line_h, xs + u * 1024);
+      if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : p.zero, xs + u * 1024);
     }
     const char* wsrc = wg + (size_t)cb * WBYTES + lane * 16;
 #pragma unroll
@@ -314,6 +314,7 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
                 (uintptr_t)d->bpacked | (uintptr_t)d->mask_src) % 16 == 0,
                "sr_conv3x3_bf16: pointers must be 16-byte aligned");
   ConvParamsH p = {};
+  p.zero = sr::zero_line();
   p.in = (const char*)d->in;
   p.w = (const char*)d->wpacked;
   p.bias = d->bpacked;

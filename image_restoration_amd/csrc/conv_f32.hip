@@ -27,9 +27,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-__device__ __attribute__((aligned(64))) float g_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct ConvParams {
+  const void* zero;  // sr::zero_line()
   const float* in;
   const float* w;
   const float* bias;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
     for (int r = 0; r < NXR; ++r) {
       const int u = r * NW + wave;
       if (u < NXU) {
-        const float* src = xoff[r] >= 0 ? plane + xoff[r] : g_zero_line;
+        const float* src = xoff[r] >= 0 ? plane + xoff[r] : (const float*)p.zero;
         glds16(src, xs + u * 1024);
       }
     }
@@ -290,11 +290,11 @@ __global__ __launch_bounds__(256) void conv_fewcout_f32_kernel(const ConvParams 
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
       const int u = r * 4 + wave;
-      if (u < NXU) glds16(xoff[r] >= 0 ? plane + xoff[r] : g_zero_line, xs + u * 1024);
+      if (u < NXU) glds16(xoff[r] >= 0 ? plane + xoff[r] : (const float*)p.zero, xs + u * 1024);
     }
     if (wave < NWU) {
       const float* wchunk = p.w + (size_t)cb * (NT * 32 * 8);
-      glds16(woff >= 0 ? wchunk + woff : g_zero_line, xs + XBYTES + wave * 1024);
+      glds16(woff >= 0 ? wchunk + woff : (const float*)p.zero, xs + XBYTES + wave * 1024);
     }
   };
 
@@ -421,6 +421,7 @@ int fill_common(const sr_conv3x3_desc* d, ConvParams* pp, const char* who) {
                "%s: pointers must be 16-byte aligned", who);
   ConvParams& p = *pp;
   p = ConvParams{};
+  p.zero = sr::zero_line();
   p.in = d->in;
   p.w = d->wpacked;
   p.bias = d->bpacked;
@@ -629,9 +630,11 @@ extern "C" const char* sr_kernel_name(int id) {
         "conv_bf16_kernelILi2ELi4ELi8ELb1E"};
     return hnames[id - 16];
   }
-  if (id >= 32 && id < 38) {  // wgrad_bf16.hip
-    static const char* gnames[6] = {"wgrad_bf16_kernelILi1ELi1ELi8E", "wgrad_bf16_kernelILi1ELi2ELi4E", "wgrad_bf16_kernelILi1ELi4ELi2E",
-                                    "wgrad_bf16_kernelILi2ELi1ELi4E", "wgrad_bf16_kernelILi2ELi2ELi2E", "wgrad_bf16_kernelILi2ELi4ELi1E"};
+  if (id >= 32 && id < 40) {  // wgrad_bf16.hip <CT, IT, KS, R, NSTG>
+    static const char* gnames[8] = {"wgrad_bf16_kernelILi1ELi1ELi8ELi2ELi4E", "wgrad_bf16_kernelILi1ELi2ELi4ELi2ELi4E",
+                                    "wgrad_bf16_kernelILi1ELi4ELi2ELi1ELi4E", "wgrad_bf16_kernelILi2ELi1ELi4ELi2ELi4E",
+                                    "wgrad_bf16_kernelILi2ELi2ELi2ELi2ELi3E", "wgrad_bf16_kernelILi2ELi4ELi1ELi1ELi4E",
+                                    "wgrad_bf16_kernelILi1ELi3ELi2ELi1ELi4E", "wgrad_bf16_kernelILi1ELi5ELi1ELi1ELi4E"};
     return gnames[id - 32];
   }
   return (id >= 0 && id < 8) ? names[id] : "";

@@ -30,6 +30,9 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
   float* db;
 };
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
+// Device address of a 64-byte line of zeros (padding source of the LDS-DMA loaders).  Kernels take it as a parameter:
+// naming the __device__ symbol inside a loop makes hipcc re-load its address (s_getpc + s_load + wait) at every use.
+const void* zero_line();
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
 
 #define SR_CHECK_ARG(cond, ...)            \

@@ -22,9 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-__device__ __attribute__((aligned(64))) float g_zero_line_w[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct WgradParams {
+  const void* zero;  // sr::zero_line()
   const float* x;   // forward source activation, CB8
   const float* dy;  // gradient wrt the conv's (pre-activation) output, CB8
   float* slab;      // [splits][pairs_in_launch][9][1024]
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
         const int gx = x0 + p.tap_ox + pix;
         const bool ok = (q < XPIECES) && vy >= 0 && vy < p.vH && gx >= 0 && gx < p.vW && cb < p.cin_blocks;
         const int sy = ((vy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
-        const float* src = ok ? xn + cb * xplane + ((long long)sy * p.x_w + sx) * 8 + (c4 & 1) * 4 : g_zero_line_w;
+        const float* src = ok ? xn + cb * xplane + ((long long)sy * p.x_w + sx) * 8 + (c4 & 1) * 4 : (const float*)p.zero;
         const int slot = u % NXR;
         glds16w(src, xring + slot * XROWB + v * 1024);
       } else {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
         const int cb = p.cout_tile0 * 4 + (c4 >> 1);
         const int gx = x0 + pix;
         const bool ok = y < p.H && gx < p.W && cb < p.cout_blocks;
-        const float* src = ok ? dyn + cb * yplane + ((long long)y * p.W + gx) * 8 + (c4 & 1) * 4 : g_zero_line_w;
+        const float* src = ok ? dyn + cb * yplane + ((long long)y * p.W + gx) * 8 + (c4 & 1) * 4 : (const float*)p.zero;
         const int slot = y % NYR;
         glds16w(src, yring + slot * YROWB + vy * 1024);
       }
@@ -523,6 +523,7 @@ int fill_wgrad(const sr_conv3x3_wgrad_desc* d, WgradParams* pp, const char* who)
                who);
   WgradParams& p = *pp;
   p = WgradParams{};
+  p.zero = sr::zero_line();
   p.x = d->x;
   p.dy = d->dy;
   p.x_ns = d->x_img_stride;

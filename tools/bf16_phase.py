@@ -32,6 +32,31 @@ def run(n, cin, cout, h, w, res=False):
           f'| prologue {float(t[:,1].mean()):.0f} | compute {float(t[:,2].mean()):.0f} | barrier-wait {float(t[:,3].mean()):.0f} '
           f'| loop total {float(t[:,4].mean()):.0f} | epilogue {float(t[:,5].mean()):.0f} | end max {float((t[:,0]+t[:,4]+t[:,5]).max()-t0):.0f} (shader cycles)')
 
+
+def run_wgrad(n, cin, cout, h, w, first_seg=None, seg=0):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    cin_pad = lib.sr_conv3x3_cin_pad16(cin, cin if first_seg is None else first_seg, seg)
+    src = ops.CB16(torch.randn(n, cin_pad // 16, h, w, 16, generator=g).to(torch.bfloat16).cuda())
+    dy = ops.CB16(torch.randn(n, (cout + 15) // 16, h, w, 16, generator=g).to(torch.bfloat16).cuda())
+    dbg = torch.zeros(1 << 18, dtype=torch.int64, device='cuda')
+    lib.sr_dev_wgrad_bf16_phase_clocks.argtypes = [C.c_void_p]
+    for it in range(3):
+        lib.sr_dev_wgrad_bf16_phase_clocks(dbg.data_ptr() if it == 2 else None)
+        ops.conv3x3_wgrad_bf16(src, dy, cout, cin, first_seg, seg)
+    lib.sr_dev_wgrad_bf16_phase_clocks(None)
+    torch.cuda.synchronize()
+    t = dbg.cpu().view(-1, 8)
+    t = t[t[:, 0] > 1e9].double()
+    t0 = t[:, 0].min()
+    print(f'wgrad n={n} cin={cin} cout={cout}: waves={len(t)} (last launch group) start spread {float(t[:,0].max()-t0):.0f} | '
+          f'first wait {float(t[:,1].mean()):.0f} | later waits {float(t[:,2].mean()):.0f} | loop end {float(t[:,3].mean()):.0f} '
+          f'| total {float(t[:,4].mean()):.0f} | steps {float(t[:,5].mean()):.0f} | end max {float((t[:,0]+t[:,4]).max()-t0):.0f} cycles')
+
+run_wgrad(16, 64, 32, 128, 128)
+run_wgrad(16, 128, 32, 128, 128, 64, 32)
+run_wgrad(16, 160, 32, 128, 128, 64, 32)
+run_wgrad(16, 128, 64, 128, 128, 64, 32)
 run(16, 160, 32, 128, 128)
 run(16, 192, 64, 128, 128, True)
 run(16, 64, 64, 128, 128)
