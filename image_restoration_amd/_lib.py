@@ -124,6 +124,9 @@ SIGNATURES = {
     'sr_conv3x3_bf16': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     'sr_conv3x3_wgrad_slab_bytes_bf16': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_wgrad_bf16': (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    'sr_rdb_wgrad_slab_bytes_bf16': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'sr_rdb_wgrad_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_void_p), C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_upsample2x_bwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_cb16_axpby_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int,

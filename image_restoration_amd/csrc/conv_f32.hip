@@ -637,5 +637,6 @@ extern "C" const char* sr_kernel_name(int id) {
                                     "wgrad_bf16_kernelILi1ELi3ELi2ELi1ELi4E", "wgrad_bf16_kernelILi1ELi5ELi1ELi1ELi4E"};
     return gnames[id - 32];
   }
+  if (id == 40) return "wgrad_rdb_bf16_kernel";
   return (id >= 0 && id < 8) ? names[id] : "";
 }

@@ -122,6 +122,8 @@ BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
   for (int i = 0; i < 4; ++i) B.g[i] = cv.take((size_t)n * ctot * hw);
   B.dxin = cv.take((size_t)n * P.cin0_pad * hw);
   B.slab_bytes = sr_conv3x3_wgrad_slab_bytes_bf16(n, 4 * h, 4 * w);
+  const size_t rdb_bytes = sr_rdb_wgrad_slab_bytes_bf16(n, h, w, c->num_feat, c->num_grow_ch);
+  if (rdb_bytes > B.slab_bytes) B.slab_bytes = rdb_bytes;
   B.slab = cv.take(B.slab_bytes / 2);
   B.bytes = cv.off;
   return B;
@@ -451,16 +453,16 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       __bf16* D = B.g[gi];  // D[0:nf] = dL/d(block output)
       __bf16* Dn = B.g[(gi + 1) & 3];
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
-      rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);  // conv5: dY5 = s5 * D[0:nf]
-      if (rc) return rc;
       for (int sl = 4; sl >= 1; --sl) {  // dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k
         __bf16* dys = D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw;
         rc = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, dys, cfg->num_grow_ch, nullptr, 0.f, nullptr, 0.f,
                   cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
         if (rc) return rc;
-        rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, dys, cat_ns, 1.f);
-        if (rc) return rc;
       }
+      // all five weight gradients of the block in one launch (conv5: dY5 = s5 * D[0:nf]); D stays intact meanwhile
+      rc = sr::rdb_wgrad_bf16(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5,
+                              accumulate, B.slab, B.slab_bytes, stream);
+      if (rc) return rc;
       // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
       rc = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
       if (rc) return rc;

@@ -22,6 +22,8 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
   float* part;
   float* bpart;
   long long splits;
+  long long split_stride;  // floats between consecutive splits of the slab (0: P*ntap*1024, dense)
+  int bsplit_stride;       // floats between consecutive splits of the bias slab (0: CT*32)
   int P, IT, CT, ntap, ks, kdim, t_mul, dy_off, dx_off, cin_tile0, cout_tile0;
   int cout, cin, first_seg, seg, seg_pad;
   float scale;
@@ -30,6 +32,8 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
   float* db;
 };
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
+int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
+                   float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream);
 // Device address of a 64-byte line of zeros (padding source of the LDS-DMA loaders).  Kernels take it as a parameter:
 // naming the __device__ symbol inside a loop makes hipcc re-load its address (s_getpc + s_load + wait) at every use.
 const void* zero_line();

@@ -299,6 +299,262 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// All five weight gradients of one residual dense block in ONE launch.  At bf16 rates these kernels run at the HBM
+// share of a CU (~25 GB/s), so what matters is bytes: a workgroup's 8 waves each own one (cout tile, cin tile) pair for
+// all taps (no k-split), and the block's 26 pairs (nf = 64, gc = 32) are packed into 4 ITEMS of <= 8 pairs that share
+// their rows — {conv5 tile0 x X0-5, conv1 x X0-1}, {conv5 tile1 x X0-5}, {conv4 x X0-4, conv2 x X0-2}, {conv3 x X0-3} —
+// so X is read 4 times and dY once per item instead of once per (conv, group) launch, the slab shrinks (one tile per
+// pair per workgroup, 64 pixel-splits) and items x splits = 256 workgroups = one round of the chip.  X is the block's
+// concat buffer for every item, dY one or two 32-channel windows of the gradient concat buffer.
+struct RdbItem {
+  int ndy;                 // 32-cout tiles of dY held by the item (1 or 2)
+  int dy_cb0_0, dy_cb0_1, dy_cbn_0, dy_cbn_1;  // first 16-channel block in D and valid blocks (<= 2) of each
+  int x_tile0, nx;         // cin tiles [x_tile0, x_tile0 + nx) of the concat buffer, nx <= 6
+  int npairs;              // <= 8: wave w owns pair w = (dY tile pa(w), X tile pb(w) relative to x_tile0)
+  unsigned pa_bits, pb_nib;  // pa(w) = bit w of pa_bits, pb(w) = nibble w of pb_nib (no arrays: a dynamically indexed
+                             // kernel-argument array is copied to scratch)
+  int bias_wave_0, bias_wave_1;  // wave that accumulates the bias gradient of dY tile a (or -1)
+  long long slab_off, bslab_off;  // float offsets of this item's tiles / bias partials
+};
+struct RdbWgradParams {
+  const void* zero;
+  const __bf16* x;
+  const __bf16* dy;
+  float* slab;
+  float* bslab;
+  long long x_ns, dy_ns;
+  int H, W, cin_blocks, strips, rows_per_wg, row_splits, nitems, splits;
+  long long* dbg;  // development: per-wave phase clocks
+};
+struct RdbItems {
+  RdbItem it[8];
+};
+
+constexpr int RDB_NSTG = 3, RDB_MAXX = 6;
+constexpr int RDB_XUNITS = (RDB_MAXX * 2 * PLP + 63) / 64, RDB_YUNITS = (2 * 2 * PLP + 63) / 64;
+constexpr int RDB_XROWB = RDB_XUNITS * 1024, RDB_YROWB = RDB_YUNITS * 1024;
+constexpr int RDB_NXR = RDB_NSTG + 2, RDB_NYR = RDB_NSTG;
+constexpr int RDB_XRING = RDB_NXR * RDB_XROWB, RDB_DUMP = RDB_XRING + RDB_NYR * RDB_YROWB;
+constexpr int RDB_L = (RDB_XUNITS + RDB_YUNITS + 7) / 8;
+constexpr int RDB_LDS = RDB_DUMP + 1024;
+static_assert(RDB_LDS <= 160 * 1024 && RDB_L * (RDB_NSTG - 2) < 64, "rdb wgrad geometry");
+
+// The item table travels as eight separate by-value arguments: an array inside the parameter struct makes hipcc copy
+// the whole struct to scratch and re-load fields inside the loop behind vmcnt(0) waits (which drain the row prefetch).
+__global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParams p, const RdbItem i0, const RdbItem i1,
+                                                             const RdbItem i2, const RdbItem i3, const RdbItem i4,
+                                                             const RdbItem i5, const RdbItem i6, const RdbItem i7) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NSTG = RDB_NSTG, NXR = RDB_NXR, NYR = RDB_NYR, XROWB = RDB_XROWB, YROWB = RDB_YROWB;
+  constexpr int XRING = RDB_XRING, DUMP = RDB_DUMP, L = RDB_L;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split_i = blockIdx.x / p.nitems;
+  const int item_i = blockIdx.x - split_i * p.nitems;
+#define RDB_SEL(f) \
+  (item_i == 0 ? i0.f : item_i == 1 ? i1.f : item_i == 2 ? i2.f : item_i == 3 ? i3.f : item_i == 4 ? i4.f : item_i == 5 ? i5.f : item_i == 6 ? i6.f : i7.f)
+  struct {
+    int ndy, dy_cb0_0, dy_cb0_1, dy_cbn_0, dy_cbn_1, x_tile0, nx, npairs;
+    long long slab_off, bslab_off;
+  } im;
+  im.ndy = RDB_SEL(ndy);
+  im.dy_cb0_0 = RDB_SEL(dy_cb0_0);
+  im.dy_cb0_1 = RDB_SEL(dy_cb0_1);
+  im.dy_cbn_0 = RDB_SEL(dy_cbn_0);
+  im.dy_cbn_1 = RDB_SEL(dy_cbn_1);
+  im.x_tile0 = RDB_SEL(x_tile0);
+  im.nx = RDB_SEL(nx);
+  im.npairs = RDB_SEL(npairs);
+  im.slab_off = RDB_SEL(slab_off);
+  im.bslab_off = RDB_SEL(bslab_off);
+  const unsigned pa_bits = RDB_SEL(pa_bits), pb_nib = RDB_SEL(pb_nib);
+  const int bw0 = RDB_SEL(bias_wave_0), bw1 = RDB_SEL(bias_wave_1);
+#undef RDB_SEL
+  const bool active = wave < im.npairs;
+  const int pa = active ? (pa_bits >> wave) & 1 : 0, pb = active ? (pb_nib >> (4 * wave)) & 15 : 0;
+  const bool bias_wave = active && (pa ? bw1 : bw0) == wave;
+  const int xunits = (im.nx * 2 * PLP + 63) / 64, yunits = (im.ndy * 2 * PLP + 63) / 64;
+
+  int t = split_i;
+  const int rs = t % p.row_splits;
+  t /= p.row_splits;
+  const int strip = t % p.strips;
+  const int n = t / p.strips;
+  const int x0 = strip * 64;
+  const int y_begin = rs * p.rows_per_wg;
+  const int y_end = min(y_begin + p.rows_per_wg, p.H);
+  const int nsteps = y_end - y_begin;
+
+  const __bf16* xn = p.x + (long long)n * p.x_ns;
+  const __bf16* dyn = p.dy + (long long)n * p.dy_ns;
+  const long long plane_e = (long long)p.H * p.W * 16;
+  char* xring = smem;
+  char* yring = smem + XRING;
+  const unsigned lds_base = (unsigned)(size_t)smem;
+
+  auto load_x = [&](int row, int v) __attribute__((always_inline)) {
+    const int vy = row - 1;
+    const int q = v * 64 + lane;
+    const int plane = q / PLP, within = q - plane * PLP;
+    const int px = within >> 1, half = within & 1;
+    const int cb = im.x_tile0 * 2 + plane;
+    const int gx = x0 - 1 + px;
+    const bool ok = plane < im.nx * 2 && px < 66 && vy >= 0 && vy < p.H && gx >= 0 && gx < p.W && cb < p.cin_blocks;
+    const void* src = ok ? (const void*)(xn + cb * plane_e + ((long long)vy * p.W + gx) * 16 + half * 8) : p.zero;
+    glds16wh(src, xring + (row % NXR) * XROWB + v * 1024);
+  };
+  auto load_y = [&](int y, int v) __attribute__((always_inline)) {
+    const int q = v * 64 + lane;
+    const int plane = q / PLP, within = q - plane * PLP;
+    const int px = within >> 1, half = within & 1;
+    const int a = plane >> 1, sub = plane & 1;
+    const int gx = x0 + px;
+    const int cbn = a ? im.dy_cbn_1 : im.dy_cbn_0, cb0 = a ? im.dy_cb0_1 : im.dy_cb0_0;
+    const bool ok = a < im.ndy && sub < cbn && px < 64 && y < y_end && gx < p.W;
+    const void* src = ok ? (const void*)(dyn + (cb0 + sub) * plane_e + ((long long)y * p.W + gx) * 16 + half * 8) : p.zero;
+    glds16wh(src, yring + (y % NYR) * YROWB + v * 1024);
+  };
+  // stage s = X tap-row y_begin + 2 + s and dY row y_begin + s; exactly L loads per wave (load uu of the stage)
+  auto issue_one = [&](int s, int uu) __attribute__((always_inline)) {
+    const bool real = s < nsteps;
+    const int u = uu * 8 + wave;
+    if (real && u < xunits)
+      load_x(y_begin + 2 + s, u);
+    else if (real && u < xunits + yunits)
+      load_y(y_begin + s, u - xunits);
+    else
+      glds16wh(p.zero, smem + DUMP);
+  };
+  auto issue = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int uu = 0; uu < L; ++uu) issue_one(s, uu);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  float bsum = 0.f;
+
+  const int grp = lane >> 4, li = lane & 15;
+  const int tq = li >> 2, tp = li & 3;
+  const int kh = grp >> 1, blk = grp & 1;
+  const int a_lane = (pa * 2 + blk) * PLB + (kh * 8 + tq) * 32 + tp * 8;
+  const int b_lane = (pb * 2 + blk) * PLB + (kh * 8 + tq) * 32 + tp * 8;
+
+  long long tk[5] = {0, 0, 0, 0, 0};
+  if (p.dbg) tk[0] = __builtin_readcyclecounter();
+  for (int u = wave; u < 2 * xunits; u += 8) load_x(y_begin + u / xunits, u % xunits);
+#pragma unroll
+  for (int s = 0; s < NSTG - 1; ++s) issue(s);
+  for (int s = 0; s < nsteps; ++s) {
+    long long tw = 0;
+    if (p.dbg) tw = __builtin_readcyclecounter();
+    wait_vmcnt_w<L*(NSTG - 2)>();
+    __builtin_amdgcn_s_barrier();
+    long long ti = 0;
+    if (p.dbg) {
+      ti = __builtin_readcyclecounter();
+      if (s == 0) tk[1] = ti - tk[0]; else tk[2] += ti - tw;
+    }
+    // The refill of the rows freed by this barrier is NOT issued here in one go: the chip-wide HBM share of a CU is
+    // what these loads wait for (they block at issue once the queue is full), and a block of loads right after the
+    // barrier stalls all eight waves at once while no MFMA runs.  They are dealt out between the k-steps below, so a
+    // wave blocked on a load leaves the SIMD to the other wave's MFMAs.
+    if (!active) issue(s + NSTG - 1);
+    if (active) {
+      // Software pipeline over (16-pixel k-step, tap row): the 6 X fragments of tap row ty+1 (and, behind the last tap
+      // row, the next k-step's dY fragments and first tap row) are in flight while the 3 MFMAs of tap row ty run, retired
+      // by counted lgkmcnt waits (LDS reads complete in order).  One wave has ~100-300 cycles of MFMA work per wait and
+      // the LDS latency under eight reading waves is longer, so the second wave of the SIMD fills the rest.
+      const int row = y_begin + s;
+      const unsigned ya = lds_base + XRING + (row % NYR) * YROWB + a_lane;
+      unsigned xb[3];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) xb[ty] = lds_base + ((row + ty) % NXR) * XROWB + b_lane;
+      s16x4 fa[2][2], fb[2][6];
+      auto read_a = [&](int seg, s16x4 (&d)[2]) __attribute__((always_inline)) {
+        d[0] = tr_read<0>(ya + seg * 512);
+        d[1] = tr_read<128>(ya + seg * 512);
+      };
+      auto read_b = [&](int seg, int ty, s16x4 (&d)[6]) __attribute__((always_inline)) {
+        const unsigned b = xb[ty] + seg * 512;
+        d[0] = tr_read<0>(b);
+        d[1] = tr_read<128>(b);
+        d[2] = tr_read<32>(b);
+        d[3] = tr_read<160>(b);
+        d[4] = tr_read<64>(b);
+        d[5] = tr_read<192>(b);
+      };
+      read_a(0, fa[0]);
+      read_b(0, 0, fb[0]);
+#pragma unroll
+      for (int seg = 0; seg < 4; ++seg) {
+        {
+          long long ti2 = 0;
+          if (p.dbg) ti2 = __builtin_readcyclecounter();
+#pragma unroll
+          for (int uu = seg; uu < L; uu += 4) issue_one(s + NSTG - 1, uu);
+          if (p.dbg) tk[4] += __builtin_readcyclecounter() - ti2;
+        }
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int cur = (seg * 3 + ty) & 1;
+          // prefetch the next group into the other buffer, then wait for the current one
+          if (ty < 2) {
+            read_b(seg, ty + 1, fb[cur ^ 1]);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          } else if (seg < 3) {
+            read_a(seg + 1, fa[(seg + 1) & 1]);
+            read_b(seg + 1, 0, fb[cur ^ 1]);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fa[seg & 1][0], fa[seg & 1][1], 0, 1, 2, 3, 4, 5, 6, 7));
+          if (ty == 0 && bias_wave) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += (float)a[e];
+          }
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fb[cur][2 * tx], fb[cur][2 * tx + 1], 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * 3 + tx], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  wait_vmcnt_w<0>();  // the tail's dummy loads still target the dump KB
+  if (p.dbg) tk[3] = __builtin_readcyclecounter() - tk[0];
+
+  if (active) {
+    float* dst = p.slab + im.slab_off + (((long long)split_i * im.npairs + wave) * 9) * 1024 + lane * 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[tap][g * 4 + e];
+        *(f32x4*)(dst + tap * 1024 + g * 256) = v;
+      }
+    if (bias_wave) {
+      bsum += __shfl_xor(bsum, 32);
+      if (kh == 0) p.bslab[im.bslab_off + ((long long)split_i * im.ndy + pa) * 32 + blk * 16 + li] = bsum;
+    }
+  }
+  if (p.dbg && lane == 0) {
+    long long* o = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_readcyclecounter() - tk[0]; o[5] = nsteps; o[6] = tk[4]; o[7] = item_i;
+  }
+}
+
 long long* g_wgrad_phase_clocks = nullptr;
 
 struct SlabCarve {
@@ -402,13 +658,234 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
 
 }  // namespace
 
+namespace sr {
+namespace {
+struct RdbRow {  // the pairs of one (conv, cout tile) over a window of cin tiles
+  int conv, cout_tile, x_tile0, nx, dy_cb0, dy_cbn;
+};
+struct RdbPlan {
+  int nitems, nrows;
+  RdbItem items[8];
+  RdbRow rows[32];
+  int row_item[32], row_pair0[32], row_a[32];
+  long long pairs;
+};
+// Greedy packing, largest rows first: a row joins the first item with room for its pairs (<= 8), a free dY slot (<= 2)
+// and the same first cin tile.  Returns false if the block needs more than 8 items.
+bool rdb_plan(int nf, int gc, float* const* dparams, RdbPlan* P) {
+  const int nfp = (nf + 15) / 16 * 16, gcp = (gc + 15) / 16 * 16;
+  P->nitems = P->nrows = 0;
+  P->pairs = 0;
+  for (int k = 5; k >= 1; --k) {  // conv5, conv4, ...: descending cin = descending row size
+    if (dparams && !dparams[2 * (k - 1)]) continue;
+    const int cout = k == 5 ? nf : gc;
+    const int its = cdiv(nfp + (k - 1) * gcp, 32), cts = cdiv(cout, 32);
+    const int dy_ch0 = k == 5 ? 0 : nfp + (4 - k) * gcp;
+    for (int c = 0; c < cts; ++c)
+      for (int i0 = 0; i0 < its; i0 += RDB_MAXX) {
+        if (P->nrows >= 32) return false;
+        RdbRow& r = P->rows[P->nrows++];
+        r.conv = k;
+        r.cout_tile = c;
+        r.x_tile0 = i0;
+        r.nx = its - i0 < RDB_MAXX ? its - i0 : RDB_MAXX;
+        r.dy_cb0 = dy_ch0 / 16 + c * 2;
+        const int left = (cout + 15) / 16 - c * 2;
+        r.dy_cbn = left < 2 ? left : 2;
+      }
+  }
+  for (int ri = 0; ri < P->nrows; ++ri) {
+    const RdbRow& r = P->rows[ri];
+    int dst = -1;
+    for (int i = 0; i < P->nitems && dst < 0; ++i) {
+      const RdbItem& im = P->items[i];
+      if (im.npairs + r.nx <= 8 && im.ndy < 2 && im.x_tile0 == r.x_tile0) dst = i;
+    }
+    if (dst < 0) {
+      if (P->nitems >= 8) return false;
+      dst = P->nitems++;
+      RdbItem& im = P->items[dst];
+      im = RdbItem{};
+      im.x_tile0 = r.x_tile0;
+      im.bias_wave_0 = im.bias_wave_1 = -1;
+    }
+    RdbItem& im = P->items[dst];
+    const int a = im.ndy++;
+    (a ? im.dy_cb0_1 : im.dy_cb0_0) = r.dy_cb0;
+    (a ? im.dy_cbn_1 : im.dy_cbn_0) = r.dy_cbn;
+    if (r.nx > im.nx) im.nx = r.nx;
+    P->row_item[ri] = dst;
+    P->row_pair0[ri] = im.npairs;
+    P->row_a[ri] = a;
+    for (int b = 0; b < r.nx; ++b) {
+      im.pa_bits |= (unsigned)a << im.npairs;
+      im.pb_nib |= (unsigned)b << (4 * im.npairs);
+      ++im.npairs;
+    }
+    P->pairs += r.nx;
+  }
+  return true;
+}
+void rdb_grid(const RdbPlan& P, int n, int h, int w, int* rows_per_wg, int* row_splits, long long* splits) {
+  const long long strips_total = (long long)n * cdiv(w, 64);
+  long long want = 256 / (strips_total * P.nitems);
+  if (want < 1) want = 1;
+  int rows = cdiv(h, (int)(want < h ? want : h));
+  *rows_per_wg = rows;
+  *row_splits = cdiv(h, rows);
+  *splits = strips_total * *row_splits;
+}
+}  // namespace
+
+size_t rdb_wgrad_slab_bytes(int n, int h, int w, int nf, int gc) {
+  RdbPlan P;
+  if (n <= 0 || h <= 0 || w <= 0 || nf <= 0 || gc <= 0 || !rdb_plan(nf, gc, nullptr, &P) || P.nitems == 0) return 0;
+  int rows, rsplits;
+  long long splits;
+  rdb_grid(P, n, h, w, &rows, &rsplits, &splits);
+  const size_t wbytes = (size_t)splits * P.pairs * 9 * 1024 * sizeof(float);
+  const size_t bbytes = (size_t)splits * 16 * 32 * sizeof(float);
+  const size_t head = wbytes > 64 * bbytes ? wbytes : 64 * bbytes;
+  return (head + head / 64 + (kPartFloats + kBpartFloats) * sizeof(float) + 3 * 4096) / 256 * 256;
+}
+
+// Weight gradients of the five convs of one residual dense block (reference rrdbnet_arch.py:21-25) in one launch:
+// cat = the block's concat buffer [x | x1..x4] (CB16), D = its gradient concat buffer [dY5 | dY4 | dY3 | dY2 | dY1]
+// (both with image stride ns elements); dparams[2k], dparams[2k+1] = fp32 dweight / dbias of conv k+1 (null weight:
+// skipped); scale5 multiplies conv5's gradient (D[0:nf] holds dL/d(out), dY5 = scale5 * that).
+int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
+                   float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream) {
+  const int nfp = (nf + 15) / 16 * 16, gcp = (gc + 15) / 16 * 16;
+  RdbPlan P;
+  if (!rdb_plan(nf, gc, dparams, &P)) {
+    set_error("rdb_wgrad_bf16: the block does not fit 8 work items (nf=%d gc=%d)", nf, gc);
+    return SR_EINVAL;
+  }
+  if (P.nitems == 0) return SR_OK;
+  const SlabCarve sc = carve_slab(slab, slab_bytes);
+  RdbWgradParams p = {};
+  RdbItems items = {};
+  p.zero = zero_line();
+  p.x = (const __bf16*)cat;
+  p.dy = (const __bf16*)D;
+  p.slab = sc.slab;
+  p.bslab = sc.bslab;
+  p.x_ns = p.dy_ns = ns;
+  p.H = h;
+  p.W = w;
+  p.cin_blocks = (nfp + 4 * gcp) / 16;
+  p.strips = cdiv(w, 64);
+  p.nitems = P.nitems;
+  p.dbg = g_wgrad_phase_clocks;
+  long long splits;
+  rdb_grid(P, n, h, w, &p.rows_per_wg, &p.row_splits, &splits);
+  p.splits = (int)splits;
+  long long soff = 0, boff = 0;
+  for (int i = 0; i < P.nitems; ++i) {
+    items.it[i] = P.items[i];
+    items.it[i].slab_off = soff;
+    items.it[i].bslab_off = boff;
+    soff += splits * P.items[i].npairs * 9 * 1024;
+    boff += splits * P.items[i].ndy * 32;
+  }
+  for (int ri = 0; ri < P.nrows; ++ri) {  // the first pair of a row that starts at cin tile 0 also sums its bias gradient
+    const RdbRow& r = P.rows[ri];
+    if (r.x_tile0 == 0 && dparams[2 * (r.conv - 1) + 1])
+      (P.row_a[ri] ? items.it[P.row_item[ri]].bias_wave_1 : items.it[P.row_item[ri]].bias_wave_0) = P.row_pair0[ri];
+  }
+  if ((size_t)soff * sizeof(float) > sc.wslab_bytes || (size_t)boff * sizeof(float) > sc.wslab_bytes / 64) {
+    set_error("rdb_wgrad_bf16: slab too small (need %zu B of tiles)", (size_t)soff * sizeof(float));
+    return SR_ENOSPACE;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_rdb_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RDB_LDS) != hipSuccess) {
+      set_error("rdb_wgrad_bf16: hipFuncSetAttribute(%d) failed", RDB_LDS);
+      return SR_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const bool prof = prof_on();
+  if (prof) {
+    sr_launch_record r = {};
+    r.kernel_id = 40;
+    r.cin = nfp + 4 * gcp;
+    r.cout = nf + 4 * gc;
+    r.n = n;
+    r.h = h;
+    r.w = w;
+    const double px = (double)n * h * w;
+    double fl = 0, by = 0;
+    for (int k = 1; k <= 5; ++k)
+      if (dparams[2 * (k - 1)]) fl += 2.0 * 9 * (nf + (k - 1) * gc) * (k == 5 ? nf : gc) * px;
+    for (int i = 0; i < P.nitems; ++i)
+      by += 2.0 * px * 32 * (P.items[i].nx + P.items[i].ndy) + 2.0 * splits * P.items[i].npairs * 9 * 4096;
+    r.flops = fl;
+    r.bytes = by;
+    prof_begin(stream, r);
+  }
+  hipLaunchKernelGGL(wgrad_rdb_bf16_kernel, dim3((unsigned)(splits * P.nitems)), dim3(512), RDB_LDS, stream, p, items.it[0],
+                     items.it[1], items.it[2], items.it[3], items.it[4], items.it[5], items.it[6], items.it[7]);
+  if (prof) prof_end(stream);
+  SR_CHECK_LAUNCH("wgrad_rdb_bf16 launch");
+  for (int ri = 0; ri < P.nrows; ++ri) {
+    const RdbRow& r = P.rows[ri];
+    const RdbItem& im = items.it[P.row_item[ri]];
+    const int k = r.conv;
+    const bool bias = r.x_tile0 == 0 && dparams[2 * (k - 1) + 1];
+    WgradReduce rr = {};
+    rr.slab = sc.slab + im.slab_off + (long long)P.row_pair0[ri] * 9 * 1024;
+    rr.split_stride = (long long)im.npairs * 9 * 1024;
+    rr.bslab = bias ? sc.bslab + im.bslab_off + P.row_a[ri] * 32 : nullptr;
+    rr.bsplit_stride = im.ndy * 32;
+    rr.part = sc.part;
+    rr.bpart = sc.bpart;
+    rr.splits = splits;
+    rr.P = r.nx;
+    rr.IT = r.nx;
+    rr.CT = 1;
+    rr.ntap = 9;
+    rr.ks = 3;
+    rr.kdim = 3;
+    rr.t_mul = 1;
+    rr.cin_tile0 = r.x_tile0;
+    rr.cout_tile0 = r.cout_tile;
+    rr.cout = k == 5 ? nf : gc;
+    rr.cin = nf + (k - 1) * gc;
+    rr.first_seg = nf;
+    rr.seg = gc;
+    rr.seg_pad = 16;
+    rr.scale = k == 5 ? scale5 : 1.f;
+    rr.accumulate = accumulate;
+    rr.dw = dparams[2 * (k - 1)];
+    rr.db = bias ? dparams[2 * (k - 1) + 1] : nullptr;
+    int rc = wgrad_reduce(rr, stream);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+}  // namespace sr
+
 // Development aid (tools/bf16_phase.py; not part of the ABI): per-wave phase clocks of the next launches.
 extern "C" void sr_dev_wgrad_bf16_phase_clocks(void* buf) { g_wgrad_phase_clocks = (long long*)buf; }
 
 extern "C" size_t sr_conv3x3_wgrad_slab_bytes_bf16(int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return 0;
+  // per-conv launches: <= max_wgs workgroups of 8 tiles; the dense-block launch (sr_rdb_wgrad_bf16 at the same n, h, w):
+  // <= 256 + strips workgroups... of <= 3 tiles each, i.e. never more than the first bound
   const size_t wbytes = max_wgs(n, w) * 8 * 9 * 1024 * sizeof(float);
   return (wbytes + wbytes / 64 + (kPartFloats + kBpartFloats) * sizeof(float) + 3 * 4096) / 256 * 256;
+}
+
+extern "C" size_t sr_rdb_wgrad_slab_bytes_bf16(int n, int h, int w, int nf, int gc) { return sr::rdb_wgrad_slab_bytes(n, h, w, nf, gc); }
+
+extern "C" int sr_rdb_wgrad_bf16(const void* cat, const void* D, int64_t img_stride, int n, int h, int w, int nf, int gc,
+                                 float* const* host_dparams, float scale5, int accumulate, void* slab, size_t slab_bytes,
+                                 void* stream) {
+  SR_CHECK_ARG(cat && D && host_dparams && slab && n > 0 && h > 0 && w > 0 && nf > 0 && gc > 0, "sr_rdb_wgrad_bf16: bad argument");
+  SR_CHECK_ARG(((uintptr_t)cat | (uintptr_t)D | (uintptr_t)slab) % 16 == 0, "sr_rdb_wgrad_bf16: pointers must be 16-byte aligned");
+  return sr::rdb_wgrad_bf16(cat, D, img_stride, n, h, w, nf, gc, host_dparams, scale5, accumulate, slab, slab_bytes,
+                            (hipStream_t)stream);
 }
 
 extern "C" int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* stream_) {

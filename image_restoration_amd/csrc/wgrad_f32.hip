@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
                                                             int e4, int splits, int chunk,
                                                             const float* __restrict__ bslab, float* __restrict__ bpart,
-                                                            int nb) {
+                                                            int nb, long long stride4, int bstride) {
   const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, splits);
   if (blockIdx.x == gridDim.x - 1) {  // the extra block column reduces the bias partials of this chunk
     if (bslab && (int)threadIdx.x < nb) {
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
       for (; s + 8 <= s1; s += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = bslab[(long long)(s + u) * nb + threadIdx.x];
+        for (int u = 0; u < 8; ++u) v[u] = bslab[(long long)(s + u) * bstride + threadIdx.x];
 #pragma unroll
         for (int u = 0; u < 8; ++u) b += v[u];
       }
-      for (; s < s1; ++s) b += bslab[(long long)s * nb + threadIdx.x];
+      for (; s < s1; ++s) b += bslab[(long long)s * bstride + threadIdx.x];
       bpart[blockIdx.y * nb + threadIdx.x] = b;
     }
     return;
@@ -245,12 +245,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= e4) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* p = slab + (long long)s0 * e4 + i;
+  const float4* p = slab + (long long)s0 * stride4 + i;
   int s = s0;
   for (; s + 8 <= s1; s += 8) {
     float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(long long)u * e4];
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)u * stride4];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       acc.x += v[u].x;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
       acc.z += v[u].z;
       acc.w += v[u].w;
     }
-    p += (long long)8 * e4;
+    p += (long long)8 * stride4;
   }
   for (; s < s1; ++s) {
     const float4 v = *p;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
     acc.y += v.y;
     acc.z += v.z;
     acc.w += v.w;
-    p += e4;
+    p += stride4;
   }
   part[(long long)blockIdx.y * e4 + i] = acc;
 }
@@ -424,7 +424,8 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   const int chunk = (int)((r.splits + sch - 1) / sch);
   sch = (int)((r.splits + chunk - 1) / chunk);
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch), dim3(256), 0, stream, (const float4*)r.slab,
-                     (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32);
+                     (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32,
+                     r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32);
   SR_CHECK_LAUNCH("wgrad_reduce1 launch");
   ReduceParams rp;
   rp.part = r.part;

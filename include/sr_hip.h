@@ -313,6 +313,13 @@ int sr_conv3x3_pack_bf16(const float* weight, const float* bias, int cout, int c
 int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream);
 size_t sr_conv3x3_wgrad_slab_bytes_bf16(int n, int h, int w);
 int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* stream);
+/* The five weight gradients of one residual dense block (rrdbnet_arch.py:21-25) in one launch: cat = the block's concat
+ * buffer [x|x1..x4], D = its gradient concat buffer [dY5|dY4|dY3|dY2|dY1] (both CB16, same image stride);
+ * host_dparams[2k], [2k+1] = fp32 dweight / dbias of conv k+1 (NULL weight: skipped); conv5's gradient is scaled by
+ * scale5.  Same results as five sr_conv3x3_wgrad_bf16 calls up to fp32 summation order. */
+size_t sr_rdb_wgrad_slab_bytes_bf16(int n, int h, int w, int nf, int gc);
+int sr_rdb_wgrad_bf16(const void* cat, const void* D, int64_t img_stride, int n, int h, int w, int nf, int gc,
+                      float* const* host_dparams, float scale5, int accumulate, void* slab, size_t slab_bytes, void* stream);
 int sr_upsample2x_bwd_bf16(const void* g, int64_t g_img_stride, void* dst, int64_t dst_img_stride, const void* mask,
                            int64_t mask_img_stride, float mask_slope, int n, int cblocks, int h, int w, void* stream);
 int sr_cb16_axpby_bf16(void* dst, int64_t dst_img_stride, const void* src, int64_t src_img_stride, float a, float b, int n,
