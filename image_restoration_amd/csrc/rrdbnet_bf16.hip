@@ -226,12 +226,12 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
 
 extern "C" size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg) {
   NetPlanH P;
-  return make_plan_h(cfg, &P) ? P.packed_bytes : 0;
+  return make_plan_h(cfg, &P) ? P.packed_bytes + sr::pack_table_bytes(P.convs.size()) : 0;
 }
 
 extern "C" size_t sr_rrdbnet_packed_dgrad_bytes_bf16(const sr_rrdbnet_cfg* cfg) {
   NetPlanH P;
-  return make_plan_h(cfg, &P) ? P.dgrad_bytes : 0;
+  return make_plan_h(cfg, &P) ? P.dgrad_bytes + sr::pack_table_bytes(P.convs.size()) : 0;
 }
 
 static size_t fwd_bytes_h(const sr_rrdbnet_cfg* cfg, int n, int h, int w, bool train) {
@@ -255,14 +255,24 @@ extern "C" int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* cons
   NetPlanH P;
   SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_pack_bf16: bad config");
   SR_CHECK_ARG(host_params && packed, "sr_rrdbnet_pack_bf16: null argument");
+  std::vector<sr::PackEntry> tab(P.convs.size());  // one launch for all images (pack_net.hip)
   for (size_t i = 0; i < P.convs.size(); ++i) {
     const ConvPlanH& cp = P.convs[i];
     SR_CHECK_ARG(host_params[2 * i] && host_params[2 * i + 1], "sr_rrdbnet_pack_bf16: null parameter %zu", i);
-    int rc = sr_conv3x3_pack_bf16(host_params[2 * i], host_params[2 * i + 1], cp.cout, cp.cin, cp.first_seg, cp.seg, 0,
-                                  (char*)packed + cp.w_off, (float*)((char*)packed + cp.b_off), stream);
-    if (rc) return rc;
+    sr::PackEntry& e = tab[i];
+    e = sr::PackEntry{};
+    e.kind = 0;
+    e.w[0] = host_params[2 * i];
+    e.bias = host_params[2 * i + 1];
+    e.out = (char*)packed + cp.w_off;
+    e.bout = (float*)((char*)packed + cp.b_off);
+    e.cout = cp.cout;
+    e.cin = cp.cin;
+    e.first_seg = cp.first_seg;
+    e.seg = cp.seg > 0 ? cp.seg : 1;
+    e.cin_pad = cp.cin_pad;
   }
-  return SR_OK;
+  return sr::pack_table_run(tab, packed, P.packed_bytes, true, (hipStream_t)stream);
 }
 
 extern "C" int sr_rrdbnet_pack_dgrad_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed_dgrad,
@@ -271,25 +281,35 @@ extern "C" int sr_rrdbnet_pack_dgrad_bf16(const sr_rrdbnet_cfg* cfg, const float
   SR_CHECK_ARG(make_plan_h(cfg, &P), "sr_rrdbnet_pack_dgrad_bf16: bad config");
   SR_CHECK_ARG(host_params && packed_dgrad, "sr_rrdbnet_pack_dgrad_bf16: null argument");
   const int n_rdb = 3 * cfg->num_block;
+  std::vector<sr::PackEntry> tab;
   for (size_t i = 0; i < P.convs.size(); ++i) {
     const ConvPlanH& cp = P.convs[i];
     SR_CHECK_ARG(host_params[2 * i], "sr_rrdbnet_pack_dgrad_bf16: null parameter %zu", i);
     if (i >= 1 && i < 1 + 5 * (size_t)n_rdb) continue;  // dense-block convs: packed per step below
-    int rc = sr_conv3x3_pack_bf16(host_params[2 * i], nullptr, cp.cout, cp.cin, cp.first_seg, cp.seg, 1,
-                                  (char*)packed_dgrad + cp.dg_off, nullptr, stream);
-    if (rc) return rc;
+    sr::PackEntry e = {};
+    e.kind = 1;
+    e.w[0] = host_params[2 * i];
+    e.out = (char*)packed_dgrad + cp.dg_off;
+    e.cout = cp.cout;
+    e.cin = cp.cin;
+    e.first_seg = cp.first_seg;
+    e.seg = cp.seg > 0 ? cp.seg : 1;
+    e.cin_pad = cp.cin_pad;
+    tab.push_back(e);
   }
-  for (int q = 0; q < n_rdb; ++q) {
-    const float* w[5];
-    for (int k = 0; k < 5; ++k) w[k] = host_params[2 * (1 + 5 * q + k)];
-    const float scale5 = (q % 3 == 2) ? 0.04f : 0.2f;  // x5*0.2 (+ the RRDB's *0.2 for rdb3), rrdbnet_arch.py:39,63
+  for (int q = 0; q < n_rdb; ++q)
     for (int s = 0; s < 5; ++s) {
-      int rc = sr::rdb_pack_dgrad_step_bf16(w, cfg->num_feat, cfg->num_grow_ch, s, scale5,
-                                            (char*)packed_dgrad + P.rdb_dg[q * 5 + s], (hipStream_t)stream);
-      if (rc) return rc;
+      sr::PackEntry e = {};
+      e.kind = 2;
+      for (int k = 0; k < 5; ++k) e.w[k] = host_params[2 * (1 + 5 * q + k)];
+      e.out = (char*)packed_dgrad + P.rdb_dg[q * 5 + s];
+      e.nf = cfg->num_feat;
+      e.gc = cfg->num_grow_ch;
+      e.s = s;
+      e.scale5 = (q % 3 == 2) ? 0.04f : 0.2f;  // x5*0.2 (+ the RRDB's *0.2 for rdb3), rrdbnet_arch.py:39,63
+      tab.push_back(e);
     }
-  }
-  return SR_OK;
+  return sr::pack_table_run(tab, packed_dgrad, P.dgrad_bytes, true, (hipStream_t)stream);
 }
 
 extern "C" int sr_rrdbnet_forward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h,

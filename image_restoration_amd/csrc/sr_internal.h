@@ -1,5 +1,6 @@
 // Internal helpers shared by the HIP translation units of libsr_hip.so (gfx950 only).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -34,6 +35,20 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
 int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
                    float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream);
+// pack_net.hip: one-launch packing of every weight image of a network
+struct PackEntry {
+  const float* w[5];  // kind 0/1: w[0] = OIHW weight; kind 2: conv1..conv5 of the dense block
+  const float* bias;  // kind 0
+  void* out;          // image
+  float* bout;        // kind 0: packed bias
+  int kind;           // 0 forward image + bias, 1 data-gradient image, 2 transposed-dense-block step
+  int cout, cin, first_seg, seg, cin_pad;
+  int nf, gc, s;
+  float scale5;
+  long long block0, elems;
+};
+size_t pack_table_bytes(size_t entries);
+int pack_table_run(std::vector<PackEntry>& entries, void* blob, size_t image_bytes, bool bf16, hipStream_t stream);
 // Device address of a 64-byte line of zeros (padding source of the LDS-DMA loaders).  Kernels take it as a parameter:
 // naming the __device__ symbol inside a loop makes hipcc re-load its address (s_getpc + s_load + wait) at every use.
 const void* zero_line();
