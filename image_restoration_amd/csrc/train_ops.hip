@@ -479,6 +479,52 @@ __global__ void psnr_finalize_kernel(const float* part, int nparts, float* out) 
   }
 }
 
+// SSIM map sum (psnr_ssim.py:49-83): 11x11 Gaussian (sigma 1.5) statistics over the valid region of the border-cropped,
+// uint8-quantised channel; one thread per output pixel, 121 taps, float accumulation of integers <= 255^2 weighted by a
+// normalised window (relative error ~1e-6, the reference computes in float64).
+struct SsimWin {
+  float w[11];
+};
+__global__ __launch_bounds__(256) void ssim_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int c, int h,
+                                                       int w, int crop, SsimWin win, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const int n = blockIdx.y;
+  const int hh = h - 2 * crop - 10, ww = w - 2 * crop - 10;  // valid region of the cropped image
+  const long long total = (long long)c * hh * ww;
+  const float C1 = 6.5025f, C2 = 58.5225f;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const int x = (int)(i % ww), y = (int)((i / ww) % hh), ch = (int)(i / ((long long)ww * hh));
+    const float* pa = a + (((long long)n * c + ch) * h + (y + crop)) * w + (x + crop);
+    const float* pb = b + (((long long)n * c + ch) * h + (y + crop)) * w + (x + crop);
+    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int dy = 0; dy < 11; ++dy) {
+      float r1 = 0.f, r2 = 0.f, r11 = 0.f, r22 = 0.f, r12 = 0.f;
+#pragma unroll
+      for (int dx = 0; dx < 11; ++dx) {
+        const float qa = rintf(fminf(fmaxf(pa[dy * w + dx], 0.f), 1.f) * 255.f);
+        const float qb = rintf(fminf(fmaxf(pb[dy * w + dx], 0.f), 1.f) * 255.f);
+        const float g = win.w[dx];
+        r1 += g * qa;
+        r2 += g * qb;
+        r11 += g * qa * qa;
+        r22 += g * qb * qb;
+        r12 += g * qa * qb;
+      }
+      const float g = win.w[dy];
+      m1 += g * r1;
+      m2 += g * r2;
+      s11 += g * r11;
+      s22 += g * r22;
+      s12 += g * r12;
+    }
+    const float v1 = s11 - m1 * m1, v2 = s22 - m2 * m2, cv = s12 - m1 * m2;
+    s += ((2.f * m1 * m2 + C1) * (2.f * cv + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2));
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(long long)n * gridDim.x + blockIdx.x] = s;
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -762,5 +808,22 @@ extern "C" int sr_psnr_sse_f32(const float* a, const float* b, int n, int c, int
   hipLaunchKernelGGL(psnr_sse_kernel, dim3(parts, n), dim3(256), 0, stream, a, b, c, h, w, crop_border, (float*)ws);
   hipLaunchKernelGGL(psnr_finalize_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, parts, sse);
   SR_CHECK_LAUNCH("psnr_sse");
+  return SR_OK;
+}
+
+extern "C" int sr_ssim_sum_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sum,
+                               void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(a && b && sum && ws && n > 0 && c > 0 && crop_border >= 0 && h > 2 * crop_border + 10 && w > 2 * crop_border + 10,
+               "sr_ssim_sum_f32: bad argument (the cropped image must be larger than the 11x11 window)");
+  const int parts = 64;
+  SR_CHECK_ARG(ws_bytes >= (size_t)n * parts * sizeof(float), "sr_ssim_sum_f32: workspace too small");
+  SsimWin win;  // cv2.getGaussianKernel(11, 1.5): exp(-(i-5)^2 / (2 sigma^2)), normalised
+  double g[11], tot = 0;
+  for (int i = 0; i < 11; ++i) tot += g[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+  for (int i = 0; i < 11; ++i) win.w[i] = (float)(g[i] / tot);
+  hipLaunchKernelGGL(ssim_sum_kernel, dim3(parts, n), dim3(256), 0, stream, a, b, c, h, w, crop_border, win, (float*)ws);
+  hipLaunchKernelGGL(psnr_finalize_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, parts, sum);
+  SR_CHECK_LAUNCH("ssim_sum");
   return SR_OK;
 }

@@ -1,2 +1,2 @@
-"""Validation metrics of the path: PSNR on uint8-rounded images, host (numpy) and device (HIP)."""
-from .psnr import calculate_psnr, psnr_device  # noqa: F401
+"""Validation metrics of the path: PSNR and SSIM on uint8-rounded images, host (numpy) and device (HIP)."""
+from .psnr import calculate_psnr, calculate_ssim, psnr_device, ssim_device  # noqa: F401

@@ -4,6 +4,8 @@ Counterpart of basicsr/models/sr_model.py:14-133,204-209 on the HIP path: same o
 (zero_grad -> forward -> pixel loss -> backward -> Adam -> EMA), same log keys."""
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from .. import optim
@@ -102,6 +104,68 @@ class SRModel(BaseModel):
             with torch.no_grad():
                 self.output = self.net_g(self.lq)
             self.net_g.train()
+
+    # ------------------------------------------------------------------ validation (sr_model.py:131-184)
+    def validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        """base_model.py:39-48: rank 0 validates when distributed."""
+        if self.opt['dist']:
+            if self.opt['rank'] == 0:
+                self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+        else:
+            self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
+        """The reference's loop (sr_model.py:135-184): per validation image feed_data -> test -> metrics, averaged over
+        the loader and logged; metric options come from opt['val']['metrics'] ({name: {type: calculate_psnr |
+        calculate_ssim, crop_border, test_y_channel}}).  PSNR / SSIM without test_y_channel are reduced on the device
+        from the fp32 output with tensor2img's quantisation (metrics/psnr.py: no device->host image copy); other
+        metric options take the reference's host route through tensor2img."""
+        import os.path as osp
+        from ..metrics import psnr_device, ssim_device
+        from ..utils.img_util import tensor2img
+        from ..utils.registry import METRIC_REGISTRY
+        dataset_name = dataloader.dataset.opt['name'] if hasattr(dataloader.dataset, 'opt') else 'val'
+        val_opt = self.opt.get('val') or {}
+        metrics = val_opt.get('metrics')
+        if metrics is not None:
+            self.metric_results = {m: 0 for m in metrics.keys()}
+        idx = -1
+        for idx, val_data in enumerate(dataloader):
+            self.feed_data(val_data)
+            self.test()
+            out, gt = self.output.detach(), getattr(self, 'gt', None)
+            if save_img:
+                import numpy as np
+                from PIL import Image
+                name = osp.splitext(osp.basename(val_data['lq_path'][0]))[0] if 'lq_path' in val_data else f'{idx:06d}'
+                vis = self.opt['path'].get('visualization', '.')
+                path = osp.join(vis, name, f'{name}_{current_iter}.png') if self.opt.get('is_train', True) else \
+                    osp.join(vis, dataset_name, f'{name}_{val_opt.get("suffix") or self.opt["name"]}.png')
+                os.makedirs(osp.dirname(path), exist_ok=True)
+                Image.fromarray(np.ascontiguousarray(tensor2img([out[0:1].cpu()], rgb2bgr=False))).save(path)
+            if metrics is not None:
+                assert gt is not None, 'validation metrics need ground truth'
+                for mname, mopt in metrics.items():
+                    mopt = dict(mopt)
+                    mtype = mopt.pop('type')
+                    crop = mopt.get('crop_border', 0)
+                    if mtype in ('calculate_psnr', 'calculate_ssim') and not mopt.get('test_y_channel', False):
+                        fn = psnr_device if mtype == 'calculate_psnr' else ssim_device
+                        self.metric_results[mname] += fn(out[0:1], gt[0:1], crop)[0]  # first image, like the reference
+                    else:
+                        sr_img, gt_img = tensor2img([out[0:1].cpu()]), tensor2img([gt[0:1].cpu()])
+                        self.metric_results[mname] += METRIC_REGISTRY.get(mtype)(sr_img, gt_img, **mopt)
+            if hasattr(self, 'gt'):
+                del self.gt
+            del self.lq, self.output
+        if metrics is not None and idx >= 0:
+            for m in self.metric_results:
+                self.metric_results[m] /= (idx + 1)
+            log = f'Validation {dataset_name}\n' + ''.join(f'\t # {m}: {v:.4f}\n' for m, v in self.metric_results.items())
+            self.logger.info(log)
+            if tb_logger:
+                for m, v in self.metric_results.items():
+                    tb_logger.add_scalar(f'metrics/{m}', v, current_iter)
 
     def get_current_visuals(self):
         out_dict = OrderedDict()

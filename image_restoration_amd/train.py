@@ -37,6 +37,16 @@ def create_train_loader(opt):
     return loader, sampler, math.ceil(total_iters / iters_per_epoch), total_iters
 
 
+def create_val_loaders(opt):
+    """One loader (batch 1, in order, rank-local) per datasets.* entry whose phase is 'val' (train.py:43-66 of the
+    reference builds them next to the train loader)."""
+    loaders = []
+    for k, v in opt['datasets'].items():
+        if v.get('phase', k.split('_')[0]) == 'val':
+            loaders.append(DataLoader(build_dataset(v), batch_size=1, shuffle=False, num_workers=0))
+    return loaders
+
+
 def load_resume_state(opt):
     """--auto_resume picks the newest experiments/<name>/training_states/*.state (train.py:68-88) and points the
     pretrain paths at the matching networks (check_resume, misc.py:94-117)."""
@@ -70,6 +80,8 @@ def train_pipeline(root_path, argv=None):
             os.makedirs(opt['path'][key], exist_ok=True)
     logger.info(dict2str(opt))
     loader, sampler, total_epochs, total_iters = create_train_loader(opt)
+    val_loaders = create_val_loaders(opt)
+    val_freq = (opt.get('val') or {}).get('val_freq')
     model = build_model(opt)
     start_epoch, current_iter = 0, 0
     if resume_state:
@@ -98,10 +110,16 @@ def train_pipeline(root_path, argv=None):
             if current_iter % save_freq == 0:
                 logger.info('Saving models and training states.')
                 model.save(epoch, current_iter)
+            if val_freq and val_loaders and current_iter % val_freq == 0:  # reference train.py:195-198
+                for vl in val_loaders:
+                    model.validation(vl, current_iter, None, (opt.get('val') or {}).get('save_img', False))
         if current_iter > total_iters:
             break
     logger.info('End of training. Save the latest model.')
     model.save(epoch=-1, current_iter=-1)
+    if (opt.get('val') or {}).get('metrics') is not None:
+        for vl in val_loaders:
+            model.validation(vl, current_iter, None, (opt.get('val') or {}).get('save_img', False))
     return model
 
 

@@ -44,4 +44,4 @@ def tensor2img(tensor, rgb2bgr=True, out_type=np.uint8, min_max=(0, 1)):
         if out_type == np.uint8:
             img = (img * 255.0).round()
         result.append(np.ascontiguousarray(img).astype(out_type))
-    return result[0] if single else result
+    return result[0] if len(result) == 1 else result  # a one-element list unwraps, like the reference (:92-94)

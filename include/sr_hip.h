@@ -220,6 +220,12 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
 int sr_psnr_sse_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sse, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* Validation SSIM numerator (psnr_ssim.py:49-128 on tensor2img outputs): per image n, sum[n] = sum over channels and the
+ * valid region of the SSIM map of the border-cropped, uint8-quantised images (11x11 Gaussian window, sigma 1.5,
+ * C1 = (0.01*255)^2, C2 = (0.03*255)^2); SSIM = sum / (c * (h-2*crop-10) * (w-2*crop-10)).  ws >= n*64 floats. */
+int sr_ssim_sum_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sum, void* ws,
+                    size_t ws_bytes, void* stream);
+
 /* out[0] = mean(x) */
 int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 /* L1Loss(loss_weight, reduction='mean') (losses.py:80-106): loss[0] = weight*mean|pred-target|;

@@ -60,6 +60,9 @@ def test_train_entry_point_runs_saves_and_resumes(cuda, tmp_path):
     opt['train']['total_iter'] = 6
     opt['train']['scheduler']['milestones'] = [4]
     opt['logger'].update(print_freq=2, save_checkpoint_freq=4)
+    opt['datasets']['val'] = dict(name='synthetic_val', type='SyntheticPairedDataset', num_samples=2, gt_size=64)
+    opt['val'] = dict(val_freq=4, save_img=False, metrics=dict(psnr=dict(type='calculate_psnr', crop_border=4, test_y_channel=False),
+                                                               ssim=dict(type='calculate_ssim', crop_border=4, test_y_channel=False)))
     p = tmp_path / 'opt.yml'
     yaml.safe_dump(opt, open(p, 'w'))
     model = train_pipeline(str(tmp_path), ['-opt', str(p)])
@@ -70,6 +73,7 @@ def test_train_entry_point_runs_saves_and_resumes(cuda, tmp_path):
     assert set(log) == {'l_g_pix', 'l_g_gan', 'l_d_real', 'l_d_fake', 'out_d_real', 'out_d_fake'}
     assert all(np.isfinite(v) for v in log.values())
     assert abs(model.get_current_learning_rate()[0] - 5e-5) < 1e-12  # milestone 4 halved 1e-4
+    assert np.isfinite(model.metric_results['psnr']) and 0 < model.metric_results['ssim'] <= 1  # validation ran (val_freq, end)
     # resume from iteration 4 and finish: same optimiser step count as the uninterrupted run
     model2 = train_pipeline(str(tmp_path), ['-opt', str(p), '--auto_resume'])
     assert model2.optimizer_g.step_count == 6 and model2.optimizer_d.step_count == 6
@@ -88,3 +92,58 @@ def test_device_psnr_matches_host(cuda):
         b = tensor2img(gt[i:i + 1], rgb2bgr=True, min_max=(0, 1))
         assert abs(got[i] - calculate_psnr(a, b, 4)) < 1e-4
     assert psnr_device(gt.to(cuda), gt.to(cuda))[0] == float('inf')
+
+
+def test_device_ssim_matches_host(cuda):
+    from image_restoration_amd.metrics import calculate_ssim, ssim_device
+    from image_restoration_amd.utils.img_util import tensor2img
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(2, 3, 48, 64, generator=g)
+    sr = (gt + 0.08 * torch.randn(2, 3, 48, 64, generator=g)).clamp(-0.1, 1.1)
+    got = ssim_device(sr.to(cuda), gt.to(cuda), crop_border=4)
+    for i in range(2):
+        a, b = tensor2img(sr[i:i + 1], rgb2bgr=True, min_max=(0, 1)), tensor2img(gt[i:i + 1], rgb2bgr=True, min_max=(0, 1))
+        assert abs(got[i] - calculate_ssim(a, b, 4)) < 2e-5, (got[i], calculate_ssim(a, b, 4))
+    assert abs(ssim_device(gt.to(cuda), gt.to(cuda))[0] - 1.0) < 1e-6
+
+
+def test_sr_model_validation_loop_device_metrics(cuda, tmp_path):
+    """SRModel.validation (reference sr_model.py:131-184): metric averages over a loader equal the host metrics of the
+    tensor2img images of the same outputs; y-channel options take the host route; images are written when asked."""
+    from image_restoration_amd.models import build_model
+    from image_restoration_amd.metrics import calculate_psnr, calculate_ssim
+    from image_restoration_amd.utils.img_util import tensor2img
+    opt = dict(name='val_test', model_type='SRModel', scale=4, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+               network_g=dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8),
+               path=dict(pretrain_network_g=None, strict_load_g=True, visualization=str(tmp_path)),
+               train=dict(ema_decay=0, optim_g=dict(type='Adam', lr=1e-4, weight_decay=0, betas=[0.9, 0.99]),
+                          scheduler=dict(type='MultiStepLR', milestones=[10], gamma=0.5), total_iter=10, warmup_iter=-1,
+                          pixel_opt=dict(type='L1Loss', loss_weight=1.0, reduction='mean')),
+               val=dict(metrics=dict(psnr=dict(type='calculate_psnr', crop_border=4, test_y_channel=False),
+                                     ssim=dict(type='calculate_ssim', crop_border=4, test_y_channel=False),
+                                     psnr_y=dict(type='calculate_psnr', crop_border=4, test_y_channel=True))))
+    model = build_model(opt)
+
+    class DS(torch.utils.data.Dataset):
+        opt = {'name': 'synthetic_val'}
+
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            return {'lq': torch.rand(3, 16, 20, generator=g), 'gt': torch.rand(3, 64, 80, generator=g), 'lq_path': f'/x/img{i}.png'}
+    loader = torch.utils.data.DataLoader(DS(), batch_size=1, shuffle=False)
+    model.validation(loader, 7, None, save_img=True)
+    ref = dict(psnr=0.0, ssim=0.0, psnr_y=0.0)
+    for data in loader:
+        model.feed_data(data)
+        model.test()
+        a, b = tensor2img([model.output.cpu()]), tensor2img([data['gt']])
+        ref['psnr'] += calculate_psnr(a, b, 4) / 3
+        ref['ssim'] += calculate_ssim(a, b, 4) / 3
+        ref['psnr_y'] += calculate_psnr(a, b, 4, test_y_channel=True) / 3
+    assert abs(model.metric_results['psnr'] - ref['psnr']) < 1e-4
+    assert abs(model.metric_results['ssim'] - ref['ssim']) < 2e-5
+    assert abs(model.metric_results['psnr_y'] - ref['psnr_y']) < 1e-9
+    assert os.path.exists(os.path.join(str(tmp_path), 'img1', 'img1_7.png'))

@@ -103,3 +103,27 @@ def test_psnr_host_matches_definition():
     assert np.isfinite(calculate_psnr(a, b, 0, test_y_channel=True))
     with pytest.raises(ValueError):
         calculate_psnr(a, b, 0, input_order='XYZ')
+
+
+def test_ssim_host_matches_direct_2d_definition():
+    """calculate_ssim (separable, valid region) against a direct 2-D correlation with the outer-product window
+    (scipy), which is what the reference's cv2.filter2D(...)[5:-5, 5:-5] computes (psnr_ssim.py:66-79; cv2 is absent
+    here, so the reference itself cannot be run: parity of this metric is pinned to the published definition only)."""
+    from scipy.signal import correlate2d
+    from image_restoration_amd.metrics import calculate_ssim
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 256, (40, 52, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.randint(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2)); g /= g.sum()
+    win = np.outer(g, g)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for ch in range(3):
+        x, y = a[4:-4, 4:-4, ch].astype(np.float64), b[4:-4, 4:-4, ch].astype(np.float64)
+        f = lambda z: correlate2d(z, win, mode='valid')
+        mx, my = f(x), f(y)
+        sxx, syy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
+        vals.append((((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))).mean())
+    assert abs(calculate_ssim(a, b, 4) - np.mean(vals)) < 1e-12
+    assert abs(calculate_ssim(a, a, 0) - 1.0) < 1e-12
+    assert abs(calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), 4, input_order='CHW') - np.mean(vals)) < 1e-12
