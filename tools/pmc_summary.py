@@ -18,7 +18,7 @@ if __name__ == '__main__':
     for p in sys.argv[1:]:
         print('#', p)
         for k, cs in summarise(p).items():
-            if 'conv3x3' not in k and 'wgrad' not in k and 'sr_' not in k:
+            if not any(t in k for t in ('conv_', 'conv3x3', 'wgrad', 'pack_table', 'reduce')):
                 continue
             short = k.split('(')[0][-60:] if 'anonymous' not in k else k[k.index('::') + 2:k.index('>(') + 1]
             print(short, {c: (len(v), sum(v) / len(v)) for c, v in cs.items()})
