@@ -1,6 +1,10 @@
 // Error reporting and ABI version of libsr_hip.so.
 #include <string.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "sr_internal.h"
 
 namespace {
@@ -10,6 +14,23 @@ thread_local char g_err[512] = "";
 __device__ __attribute__((aligned(64))) float g_sr_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace sr {
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& d : done)
+    if (d.first == kernel && d.second == dev) return SR_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(%d B of LDS): %s", bytes, hipGetErrorString(e));
+    return SR_ELAUNCH;
+  }
+  done.emplace_back(kernel, dev);
+  return SR_OK;
+}
+
 const void* zero_line() {
   static void* cache[64] = {};
   int dev = 0;

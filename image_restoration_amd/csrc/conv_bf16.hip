@@ -261,15 +261,8 @@ template <int COT, int PT, int NW, bool NCHW_OUT>
 int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
   constexpr int lds = conv_bf16_lds<COT, PT, NW>();
   static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-  static bool attr_set = false;
   auto kern = conv_bf16_kernel<COT, PT, NW, NCHW_OUT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      sr::set_error("sr_conv3x3_bf16: hipFuncSetAttribute(%d) failed", lds);
-      return SR_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   p.tiles_x = sr::cdiv(p.W, 32);
   p.tiles_y = sr::cdiv(p.H, NW * PT);
   const bool prof = sr::prof_on();

@@ -359,16 +359,8 @@ constexpr int conv_lds_bytes() {
 template <int COT, int PT, int KS, bool NCHW_OUT>
 int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
   constexpr int lds = conv_lds_bytes<COT, PT, KS>();
-  static bool attr_set = false;
   auto kern = conv_f32_kernel<COT, PT, KS, NCHW_OUT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      sr::set_error("hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-      return SR_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   dim3 grid(p.tiles_x * p.tiles_y * n, groups);
   const bool prof = sr::prof_on();
   if (prof) {
@@ -483,15 +475,8 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
     // few couts, plain NCHW output: the 4x4x1 kernel (16-row tiles)
     constexpr int XB = (((16 + 2) * 34 * 32 + 1023) / 1024) * 1024, WB = ((9 * 4 * 32 + 1023) / 1024) * 1024;
     constexpr int lds = 2 * (XB + WB);
-    static bool attr_set = false;
     auto kern = conv_fewcout_f32_kernel<3>;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-        sr::set_error("sr_conv3x3_f32: hipFuncSetAttribute(%d) failed", lds);
-        return SR_ELAUNCH;
-      }
-      attr_set = true;
-    }
+    if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
     p.tiles_y = sr::cdiv(p.H, 16);
     const bool prof = sr::prof_on();
     if (prof) {

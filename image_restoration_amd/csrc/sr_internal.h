@@ -52,6 +52,9 @@ int pack_table_run(std::vector<PackEntry>& entries, void* blob, size_t image_byt
 // Device address of a 64-byte line of zeros (padding source of the LDS-DMA loaders).  Kernels take it as a parameter:
 // naming the __device__ symbol inside a loop makes hipcc re-load its address (s_getpc + s_load + wait) at every use.
 const void* zero_line();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): a per-kernel `static bool` would leave the
+// second device of a process without the attribute.
+int ensure_dynamic_lds(const void* kernel, int bytes);
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
 
 #define SR_CHECK_ARG(cond, ...)            \

@@ -603,14 +603,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
   p.bslab = want_bias ? sc.bslab : nullptr;
   p.dbg = g_wgrad_phase_clocks;
   auto kern = wgrad_bf16_kernel<CT, IT, KS, R, NSTG>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      sr::set_error("wgrad_bf16: hipFuncSetAttribute(%d) failed", lds);
-      return SR_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
@@ -797,14 +790,7 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
     set_error("rdb_wgrad_bf16: slab too small (need %zu B of tiles)", (size_t)soff * sizeof(float));
     return SR_ENOSPACE;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad_rdb_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RDB_LDS) != hipSuccess) {
-      set_error("rdb_wgrad_bf16: hipFuncSetAttribute(%d) failed", RDB_LDS);
-      return SR_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (int rc = sr::ensure_dynamic_lds((const void*)wgrad_rdb_bf16_kernel, RDB_LDS)) return rc;  // once per (kernel, device)
   const bool prof = prof_on();
   if (prof) {
     sr_launch_record r = {};

@@ -356,14 +356,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   p.slab = slab;
   p.bslab = want_bias ? bslab : nullptr;
   auto kern = wgrad_f32_kernel<CT, IT, R, KT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      sr::set_error("wgrad: hipFuncSetAttribute(%d) failed", lds);
-      return SR_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};

@@ -38,6 +38,7 @@ int main() {
       hipMemset(in, 0x3c, (size_t)N * cin * H * W * 4);  // ~0.011 floats
       hipMemset(w, 0x3c, (size_t)cout * cin * 9 * 4);
       ConvParams p = {};
+      p.zero = sr::zero_line();
       p.in = in; p.w = w; p.out = out;
       p.in_ns = (long long)cin * H * W; p.out_ns = (long long)cout * H * W;
       p.cin_blocks = cin / 8; p.cout_blocks = cout / 8; p.cout = cout;
