@@ -268,7 +268,7 @@ int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = 16 + (COT - 1) * 2 + (PT == 4 ? 1 : 0) + (NCHW_OUT ? 4 : 0) + (NW == 8 ? 8 : 0);
+    r.kernel_id = PT == 1 ? 42 + (COT - 1) : 16 + (COT - 1) * 2 + (PT == 4 ? 1 : 0) + (NCHW_OUT ? 4 : 0) + (NW == 8 ? 8 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
@@ -348,10 +348,31 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
     if (gc == 64) return w8 ? launch_h<2, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, true>(p, d->n, groups, stream, d);
     return w8 ? launch_h<1, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, true>(p, d->n, groups, stream, d);
   }
+  // Tile height by launch size: 32-row tiles (8 waves) while they still give every CU a workgroup; smaller inputs
+  // (single plate crops, 32x32 training patches) fall to 16-, 8- and 4-row tiles, which cost more halo / weight refill
+  // per MFMA but keep CUs from idling while a few workgroups walk K serially.
+  auto wgs = [&](int rows) { return (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, rows) * d->n * groups; };
+  int rows;
+  if (w8 && wgs(32) >= 256)
+    rows = 32;
+  else if (p.H % 16 == 0 && wgs(16) >= 256)
+    rows = 16;
+  else if (wgs(8) >= 256 || p.H <= 4)
+    rows = 8;
+  else
+    rows = 4;
   if (gc == 64) {
-    if (w8) return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);
-    return p.H % 16 == 0 ? launch_h<2, 4, 4, false>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, false>(p, d->n, groups, stream, d);
+    switch (rows) {
+      case 32: return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);
+      case 16: return launch_h<2, 4, 4, false>(p, d->n, groups, stream, d);
+      case 8: return launch_h<2, 2, 4, false>(p, d->n, groups, stream, d);
+      default: return launch_h<2, 1, 4, false>(p, d->n, groups, stream, d);
+    }
   }
-  if (w8) return launch_h<1, 4, 8, false>(p, d->n, groups, stream, d);
-  return p.H % 16 == 0 ? launch_h<1, 4, 4, false>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, false>(p, d->n, groups, stream, d);
+  switch (rows) {
+    case 32: return launch_h<1, 4, 8, false>(p, d->n, groups, stream, d);
+    case 16: return launch_h<1, 4, 4, false>(p, d->n, groups, stream, d);
+    case 8: return launch_h<1, 2, 4, false>(p, d->n, groups, stream, d);
+    default: return launch_h<1, 1, 4, false>(p, d->n, groups, stream, d);
+  }
 }

@@ -365,7 +365,7 @@ int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = PT == 4 ? 13 : (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
+    r.kernel_id = PT == 4 ? 13 : PT == 1 ? (COT == 1 ? 15 : 41) : (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
@@ -498,6 +498,13 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
     return SR_OK;
   }
   if (d->out_nchw) return launch<1, PT, 3, true>(p, d->n, groups, stream, d);
+  // Small inputs (single plate crops, 32x32 training patches): with 8-row tiles the launch has fewer workgroups than the
+  // chip has CUs and every layer is a serial walk over K on a few CUs; 4-row tiles double the workgroups (more halo and
+  // weight refill per MFMA, irrelevant while CUs idle).
+  if ((long long)p.tiles_x * p.tiles_y * d->n * groups < 256 && p.H > 4) {
+    p.tiles_y = sr::cdiv(p.H, 4);
+    return gc == 64 ? launch<2, 1, 3, false>(p, d->n, groups, stream, d) : launch<1, 1, 3, false>(p, d->n, groups, stream, d);
+  }
   if (gc == 64) return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
   // 32-cout groups: 16-row tiles (PT = 4) halve the weight refill per MFMA (measured +2.5..7 % on the RDB conv1-4
   // shapes, tools/conv_ablate.hip) as long as the launch still has >= 2 workgroups per CU and rows are not wasted.
@@ -623,5 +630,9 @@ extern "C" const char* sr_kernel_name(int id) {
     return gnames[id - 32];
   }
   if (id == 40) return "wgrad_rdb_bf16_kernel";
+  if (id == 42) return "conv_bf16_kernelILi1ELi1ELi4ELb0E";
+  if (id == 43) return "conv_bf16_kernelILi2ELi1ELi4ELb0E";
+  if (id == 15) return "conv_f32_kernelILi1ELi1ELi3ELb0E";
+  if (id == 41) return "conv_f32_kernelILi2ELi1ELi3ELb0E";
   return (id >= 0 && id < 8) ? names[id] : "";
 }
