@@ -25,6 +25,7 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
   long long splits;
   long long split_stride;  // floats between consecutive splits of the slab (0: P*ntap*1024, dense)
   int bsplit_stride;       // floats between consecutive splits of the bias slab (0: CT*32)
+  int groups, gi;          // multi-group launches: groups = rows x gi tile groups behind one another in the slab (0: 1)
   int P, IT, CT, ntap, ks, kdim, t_mul, dy_off, dx_off, cin_tile0, cout_tile0;
   int cout, cin, first_seg, seg, seg_pad;
   float scale;

@@ -36,6 +36,7 @@ struct WgradParams {
   int cout_blocks;  // valid channel blocks of dy
   int cin_tile0;    // first 32-channel cin tile of this launch
   int cout_tile0;   // first 32-channel cout tile of this launch
+  int gi;           // cin groups per cout-group row: group blockIdx.y = (row blockIdx.y / gi, column blockIdx.y % gi)
   int strips;       // column strips per image = ceil(W/32)
   int rows_per_wg;  // multiple of R
   int row_splits;   // ceil(H / rows_per_wg)
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int ct = wave / (IT * KS), it = (wave / KS) % IT, ks = wave % KS;
+  // one launch covers a grid of same-shaped (CT x IT) tile groups: blockIdx.y walks them
+  const int grow = blockIdx.y / p.gi, gcol = blockIdx.y - grow * p.gi;
+  const int cout_tile0 = p.cout_tile0 + grow * CT, cin_tile0 = p.cin_tile0 + gcol * IT;
 
   int t = blockIdx.x;
   const int rs = t % p.row_splits;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
         const int vy = u + p.tap_oy;  // virtual source row; outside [0, vH) = zero row
         const int q = v * 64 + lane;
         const int pix = q / (XCH / 4), c4 = q % (XCH / 4);
-        const int cb = p.cin_tile0 * 4 + (c4 >> 1);
+        const int cb = cin_tile0 * 4 + (c4 >> 1);
         const int gx = x0 + p.tap_ox + pix;
         const bool ok = (q < XPIECES) && vy >= 0 && vy < p.vH && gx >= 0 && gx < p.vW && cb < p.cin_blocks;
         const int sy = ((vy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
         const int y = yy + r;
         const int q = vy * 64 + lane;
         const int pix = q / (YCH / 4), c4 = q % (YCH / 4);
-        const int cb = p.cout_tile0 * 4 + (c4 >> 1);
+        const int cb = cout_tile0 * 4 + (c4 >> 1);
         const int gx = x0 + pix;
         const bool ok = y < p.H && gx < p.W && cb < p.cout_blocks;
         const float* src = ok ? dyn + cb * yplane + ((long long)y * p.W + gx) * 8 + (c4 & 1) * 4 : (const float*)p.zero;
@@ -199,8 +203,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 
   // write this wave's partial tile:  slab[split][pair][tap][g][lane][4]
   const int pair = ct * IT + it;
+  // slab[group][split][pair][tap][1024]; bias partials per cout-group ROW: bslab[row][split][CT][32] (column 0 writes)
+  const long long nsplit = (long long)gridDim.x * KS;
   const long long split = (long long)blockIdx.x * KS + ks;
-  float* dst = p.slab + ((split * P + pair) * (KT * KT)) * 1024 + lane * 4;
+  float* dst = p.slab + (((blockIdx.y * nsplit + split) * P + pair) * (KT * KT)) * 1024 + lane * 4;
 #pragma unroll
   for (int tap = 0; tap < KT * KT; ++tap)
 #pragma unroll
@@ -210,9 +216,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
       for (int e = 0; e < 4; ++e) v[e] = acc[tap][g * 4 + e];
       *(f32x4*)(dst + tap * 1024 + g * 256) = v;
     }
-  if (p.bslab && it == 0) {
+  if (p.bslab && it == 0 && gcol == 0) {
     bsum += __shfl_xor(bsum, 32);
-    if (h == 0) p.bslab[(split * CT + ct) * 32 + j] = bsum;
+    if (h == 0) p.bslab[((grow * nsplit + split) * CT + ct) * 32 + j] = bsum;
   }
 }
 
@@ -224,10 +230,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
                                                             int e4, int splits, int chunk,
                                                             const float* __restrict__ bslab, float* __restrict__ bpart,
-                                                            int nb, long long stride4, int bstride) {
+                                                            int nb, long long stride4, int bstride, int gi) {
+  // blockIdx.z = tile group of a multi-group launch: its slab / part blocks follow each other; bias per group row
+  const int grp = blockIdx.z, sch = gridDim.y;
+  slab += (long long)grp * splits * stride4;
+  part += (long long)grp * sch * e4;
+  if (bslab) {
+    bslab += (long long)(grp / gi) * splits * bstride;
+    bpart += (long long)(grp / gi) * sch * nb;
+  }
   const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, splits);
   if (blockIdx.x == gridDim.x - 1) {  // the extra block column reduces the bias partials of this chunk
-    if (bslab && (int)threadIdx.x < nb) {
+    if (bslab && grp % gi == 0 && (int)threadIdx.x < nb) {
       float b = 0.f;
       int s = s0;
       for (; s + 8 <= s1; s += 8) {
@@ -277,6 +291,7 @@ struct ReduceParams {
   float* dw;           // [cout][cin][3][3]
   float* db;           // [cout] or null
   int sch, splits, P, IT, CT;
+  int gi;                      // cin groups per cout-group row of a multi-group launch (blockIdx.y = group)
   int ntap, ks;                // taps per pair (ks*ks) and tap-grid width
   int kdim, t_mul, dy_off, dx_off;  // kernel position of tap (ty,tx): (ty*t_mul+dy_off, tx*t_mul+dx_off) in a kdim x kdim kernel
   int cin_tile0, cout_tile0;
@@ -289,14 +304,17 @@ struct ReduceParams {
 __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_split = p.P * p.ntap * 1024;
+  const int grp = blockIdx.y, grow = grp / p.gi, gcol = grp - grow * p.gi;
+  const int cout_tile0 = p.cout_tile0 + grow * p.CT, cin_tile0 = p.cin_tile0 + gcol * p.IT;
   if (idx < per_split) {
     float s = 0.f;
-    for (int k = 0; k < p.sch; ++k) s += p.part[(long long)k * per_split + idx];
+    const float* part = p.part + (long long)grp * p.sch * per_split;
+    for (int k = 0; k < p.sch; ++k) s += part[(long long)k * per_split + idx];
     const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3;
     const int tap = (idx >> 10) % p.ntap, pair = idx / (p.ntap * 1024);
     const int ct = pair / p.IT, it = pair % p.IT;
-    const int co = (p.cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5) + e;
-    const int pos = (p.cin_tile0 + it) * 32 + (lane & 31);
+    const int co = (cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5) + e;
+    const int pos = (cin_tile0 + it) * 32 + (lane & 31);
     // invert the concat position map of sr_conv3x3_pack_f32
     int ci = -1;
     const int fsp = (p.first_seg + p.seg_pad - 1) / p.seg_pad * p.seg_pad;
@@ -313,10 +331,11 @@ __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
       *o = p.accumulate ? *o + s * p.scale : s * p.scale;
     }
   }
-  if (p.db && p.bpart && idx < p.CT * 32) {
+  if (p.db && p.bpart && gcol == 0 && idx < p.CT * 32) {
     float s = 0.f;
-    for (int k = 0; k < p.sch; ++k) s += p.bpart[k * p.CT * 32 + idx];
-    const int co = p.cout_tile0 * 32 + idx;
+    const float* bpart = p.bpart + (long long)grow * p.sch * p.CT * 32;
+    for (int k = 0; k < p.sch; ++k) s += bpart[k * p.CT * 32 + idx];
+    const int co = cout_tile0 * 32 + idx;
     if (co < p.cout) p.db[co] = p.accumulate ? p.db[co] + s * p.scale : s * p.scale;
   }
 }
@@ -332,25 +351,30 @@ struct TapMap {
 };
 
 template <int CT, int IT, int R, int KT>
-int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, float* slab, float* bslab,
-                 bool want_bias, const TapMap& tm, hipStream_t stream) {
+int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, int grows, int gi, float* slab,
+                 float* bslab, bool want_bias, const TapMap& tm, hipStream_t stream) {
+  // One launch covers grows x gi same-shaped tile groups (grid.y), starting at (cout_tile0, cin_tile0), and ONE slab
+  // reduction: wide convs (the 512-channel discriminator layers: 64 groups x 4 parity passes) used to cost a launch
+  // and two reduce launches per group.
   constexpr int P = CT * IT, KS = 4 / P, NT = KT * KT;
   constexpr int lds = wgrad_lds_bytes<CT, IT, R, KT>();
+  const int groups = grows * gi;
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
+  p.gi = gi;
   // rows per workgroup: aim at >= 512 workgroups (2 per CU), multiple of R, at least 4R rows to amortise the prologue
   const long long strips_total = (long long)d->n * p.strips;
   int rows = p.H;
-  while (rows > 4 * R && strips_total * sr::cdiv(p.H, rows) < 512) rows = (rows + 1) / 2;
+  while (rows > 4 * R && strips_total * sr::cdiv(p.H, rows) * groups < 512) rows = (rows + 1) / 2;
   rows = (rows + R - 1) / R * R;
   p.rows_per_wg = rows;
   p.row_splits = sr::cdiv(p.H, rows);
   const long long nwg = strips_total * p.row_splits;
   const long long splits = nwg * KS;
-  if ((size_t)splits * P * NT * 1024 * sizeof(float) > d->slab_bytes ||
-      (size_t)splits * CT * 32 * sizeof(float) > d->slab_bytes / 63) {
+  if ((size_t)groups * splits * P * NT * 1024 * sizeof(float) > d->slab_bytes ||
+      (size_t)grows * splits * CT * 32 * sizeof(float) > d->slab_bytes / 63) {
     sr::set_error("sr_conv3x3_wgrad_f32: slab %zu B too small (need %zu B)", d->slab_bytes,
-                  (size_t)splits * P * NT * 1024 * sizeof(float));
+                  (size_t)groups * splits * P * NT * 1024 * sizeof(float));
     return SR_ENOSPACE;
   }
   p.slab = slab;
@@ -368,11 +392,11 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
     r.w = p.W;
     const double px = (double)d->n * p.H * p.W;
     const int cin_eff = min(32 * IT, d->cin_pad - 32 * cin_tile0), cout_eff = min(32 * CT, d->cout - 32 * cout_tile0);
-    r.flops = 2.0 * NT * cin_eff * cout_eff * px;
-    r.bytes = 4.0 * px * (cin_eff + cout_eff);
+    r.flops = 2.0 * NT * cin_eff * cout_eff * px * groups;
+    r.bytes = 4.0 * px * (cin_eff + cout_eff) * groups;
     sr::prof_begin(stream, r);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)groups), dim3(256), lds, stream, p);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("wgrad3x3_f32 launch");
   // stage 1 partials live behind the bias slab
@@ -382,6 +406,8 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   rr.part = (float*)((char*)bslab + d->slab_bytes / 63 / 256 * 256);
   rr.bpart = rr.part + (size_t)64 * 4 * 9 * 1024;  // behind the weight partials
   rr.splits = splits;
+  rr.groups = groups;
+  rr.gi = gi;
   rr.P = P;
   rr.IT = IT;
   rr.CT = CT;
@@ -412,13 +438,23 @@ namespace sr {
 // (both leave fp32 partial tiles in the 32x32 MFMA accumulator layout).  part holds 64 * P*ntap*1024 floats.
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   const int e4 = r.P * r.ntap * 256;
+  const int groups = r.groups > 0 ? r.groups : 1, gi = r.gi > 0 ? r.gi : 1;
   int sch = (int)((r.splits + 63) / 64);
-  if (sch > 64) sch = 64;
+  // part holds 64 * 4*9*1024 floats and bpart 64*64: shrink the stage-1 fan-out of multi-group launches to fit
+  int cap = (int)((size_t)64 * 4 * 9 * 1024 / ((size_t)groups * r.P * r.ntap * 1024));
+  const int bcap = 4096 / ((groups / gi) * r.CT * 32);
+  if (bcap < cap) cap = bcap;
+  if (cap < 1) {
+    set_error("wgrad_reduce: %d groups do not fit the partial buffers", groups);
+    return SR_EINVAL;
+  }
+  if (cap > 64) cap = 64;
+  if (sch > cap) sch = cap;
   const int chunk = (int)((r.splits + sch - 1) / sch);
   sch = (int)((r.splits + chunk - 1) / chunk);
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch), dim3(256), 0, stream, (const float4*)r.slab,
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch, groups), dim3(256), 0, stream, (const float4*)r.slab,
                      (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32,
-                     r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32);
+                     r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32, gi);
   SR_CHECK_LAUNCH("wgrad_reduce1 launch");
   ReduceParams rp;
   rp.part = r.part;
@@ -430,6 +466,7 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   rp.P = r.P;
   rp.IT = r.IT;
   rp.CT = r.CT;
+  rp.gi = gi;
   rp.ntap = r.ntap;
   rp.ks = r.ks;
   rp.kdim = r.kdim;
@@ -445,7 +482,7 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   rp.seg_pad = r.seg_pad;
   rp.scale = r.scale;
   rp.accumulate = r.accumulate;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((r.P * r.ntap * 1024 + 255) / 256), dim3(256), 0, stream, rp);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((r.P * r.ntap * 1024 + 255) / 256, groups), dim3(256), 0, stream, rp);
   SR_CHECK_LAUNCH("wgrad_reduce2 launch");
   return SR_OK;
 }
@@ -476,36 +513,56 @@ int run_groups(const sr_conv3x3_wgrad_desc* d, const WgradParams& p, int cin_pad
   float* bslab = (float*)((char*)d->slab + wslab_bytes);
   sr_conv3x3_wgrad_desc dd = *d;
   dd.slab_bytes = wslab_bytes;
-  for (int c0 = 0; c0 < cts;) {
-    const int cn = (cts - c0 >= 2) ? 2 : 1;
-    for (int i0 = 0; i0 < its;) {
-      const int left = its - i0;
-      const bool bias = want_bias && d->dbias != nullptr && i0 == 0;
-      int rc, in;
-      if (cn == 2) {
-        if (left >= 2) {
-          in = 2;
-          rc = launch_group<2, 2, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
-        } else {
-          in = 1;
-          rc = launch_group<2, 1, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
-        }
-      } else {
-        if (left >= 4) {
-          in = 4;
-          rc = launch_group<1, 4, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
-        } else if (left >= 2) {
-          in = 2;
-          rc = launch_group<1, 2, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
-        } else {
-          in = 1;
-          rc = launch_group<1, 1, 1, KT>(&dd, p, c0, i0, slab, bslab, bias, tm, stream);
-        }
-      }
+  // Same-shaped groups of the (cout tile, cin tile) grid go out as ONE launch each: all 2-row x 2-column groups, then
+  // the odd cin column of those rows, then the odd cout row (4-, 2-, 1-column groups).  A launch is cut into row chunks
+  // when its tiles would not fit the slab.
+  const long long strips_total = (long long)d->n * p.strips;
+  auto row_chunk = [&](int rows_left, int gi, int P_) {  // group rows per launch that fit slab + partial buffers
+    // launch_group uses < 1024 workgroups in total while strips * groups <= 512, else strips workgroups per group
+    const long long cap = (long long)(wslab_bytes / ((size_t)4 * 9 * 1024 * sizeof(float)));
+    long long fit = cap / strips_total;
+    if (fit < 1) fit = 1;
+    long long rows = fit / gi;
+    if (rows < 1) rows = 1;
+    long long rows_part = 64 * 4 / ((long long)gi * P_);  // groups * P <= 256: at least one stage-1 chunk per group
+    if (rows_part < 1) rows_part = 1;
+    if (rows > rows_part) rows = rows_part;
+    if (rows > 64) rows = 64;  // bias partials: rows * CT * 32 floats per chunk in a 4096-float buffer
+    return (int)(rows < rows_left ? rows : rows_left);
+  };
+  const int rows2 = cts / 2;  // cout-group rows of two tiles
+  for (int r0 = 0; r0 < rows2;) {
+    const int gi = its / 2;
+    const int nr = row_chunk(rows2 - r0, gi > 0 ? gi : 1, 4);
+    const bool bias = want_bias && d->dbias != nullptr;
+    if (gi > 0) {
+      int rc = launch_group<2, 2, 1, KT>(&dd, p, 2 * r0, 0, nr, gi, slab, bslab, bias, tm, stream);
       if (rc) return rc;
-      i0 += in;
     }
-    c0 += cn;
+    if (its % 2) {
+      int rc = launch_group<2, 1, 1, KT>(&dd, p, 2 * r0, its - 1, nr, 1, slab, bslab, bias && gi == 0, tm, stream);
+      if (rc) return rc;
+    }
+    r0 += nr;
+  }
+  if (cts % 2) {
+    const int c0 = cts - 1;
+    int i0 = 0;
+    const bool bias = want_bias && d->dbias != nullptr;
+    if (its / 4 > 0) {
+      int rc = launch_group<1, 4, 1, KT>(&dd, p, c0, 0, 1, its / 4, slab, bslab, bias, tm, stream);
+      if (rc) return rc;
+      i0 = its / 4 * 4;
+    }
+    if (its - i0 >= 2) {
+      int rc = launch_group<1, 2, 1, KT>(&dd, p, c0, i0, 1, 1, slab, bslab, bias && i0 == 0, tm, stream);
+      if (rc) return rc;
+      i0 += 2;
+    }
+    if (its - i0 >= 1) {
+      int rc = launch_group<1, 1, 1, KT>(&dd, p, c0, i0, 1, 1, slab, bslab, bias && i0 == 0, tm, stream);
+      if (rc) return rc;
+    }
   }
   return SR_OK;
 }
