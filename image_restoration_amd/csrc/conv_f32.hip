@@ -55,6 +55,11 @@ struct ConvParams {
   int res_cb1;      // residuals apply to destination blocks [0, res_cb1)
   float slope, alpha, beta1, beta2, mask_slope;
   int accumulate;
+  // Stacked mode (small feature maps, WT < 32): the n images are treated as ONE image of n*stack_hs rows — image i
+  // occupies virtual rows [i*stack_hs, i*stack_hs + H) and row i*stack_hs + H is a separator that reads as zero padding
+  // for both neighbours (one pad row is all a 3x3 / parity-2x2 tap grid needs) — so tiles are not confined to one tiny
+  // image.  0 = off (tiles of one image, image index from the grid).
+  int stack_hs, stack_n;
 };
 
 __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
@@ -65,10 +70,13 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
 // ABL: timing-only ablation bits for tools/conv_ablate.hip (never instantiated non-zero in the library):
 //   1 = no LDS-DMA refill in the loop, 2 = no per-chunk barrier, 8 = no output store
 // NW = waves per workgroup (4 or 8): 8 waves share one staged weight chunk over twice the rows.
-template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4>
+// WT = tile width in pixels (32, 16, 8): an MFMA column group of 32 pixels is 32/WT tile rows x WT columns, so maps
+//      narrower than 32 pixels (the 16x16 ... 4x4 layers of VGGStyleDiscriminator128) do not idle 50-88 % of the lanes.
+template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4, int WT = 32>
 __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TH = NW * PT, XROW = 32 + KS - 1, XPIX = (TH + KS - 1) * XROW;
+  constexpr int RPG = 32 / WT;  // tile rows per MFMA column group
+  constexpr int TH = NW * PT * RPG, XROW = WT + KS - 1, XPIX = (TH + KS - 1) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
   constexpr int NXU = XBYTES / 1024, NWU = KS * KS * COT;
   constexpr int WBYTES = NWU * 1024, STAGE = XBYTES + WBYTES;
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
+  const int jr = j / WT, jc = j % WT;  // this lane's pixel inside a column group
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each
   // XCD a contiguous run of tiles (neighbouring tiles share halo rows and weights in L2).
@@ -89,11 +98,13 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
-  const int n = t / p.tiles_y;
+  const int n_grid = t / p.tiles_y;
+  const int n = n_grid;
   const int cog = blockIdx.y;
-  const int x0 = tx * 32, y0 = ty * TH;
+  const int x0 = tx * WT, y0 = ty * TH;
   const int HWin = p.in_h * p.in_w;
-  const float* in_n = p.in + (long long)n * p.in_ns;
+  const bool stacked = WT < 32 && p.stack_hs > 0;
+  const float* in_n = p.in + (stacked ? 0 : (long long)n * p.in_ns);
   const float* wg = p.w + (size_t)cog * p.cin_blocks * (WBYTES / 4);
 
   // Per-lane source offsets (floats, inside one channel-block plane) of the X pieces this
@@ -105,10 +116,19 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
     const int q = u * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
-    const int gy = y0 + p.tap_oy + row, gx = x0 + p.tap_ox + col;
-    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.vH && gx >= 0 && gx < p.vW;
+    int gy = y0 + p.tap_oy + row;
+    const int gx = x0 + p.tap_ox + col;
+    int img_off = 0;
+    bool valid = (pix < XPIX) && gx >= 0 && gx < p.vW;
+    if (stacked) {  // virtual row -> (image, row); the separator row and everything outside the stack read as zero
+      const int img = gy >= 0 ? gy / p.stack_hs : -1;
+      gy -= img * p.stack_hs;
+      valid = valid && img >= 0 && img < p.stack_n;
+      img_off = img * (int)p.in_ns;
+    }
+    valid = valid && gy >= 0 && gy < p.vH;
     const int sy = ((gy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
-    xoff[r] = valid ? ((sy * p.in_w + sx) * 8 + half * 4) : -1;
+    xoff[r] = valid ? (img_off + (sy * p.in_w + sx) * 8 + half * 4) : -1;
   }
 
   auto stage = [&](int buf, int cb) {
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  const int xlane = ((wave * PT) * XROW + j) * 32 + h * 16;  // byte offset of this lane's B operand, tap (0,0), row 0
+  const int xlane = ((wave * PT * RPG + jr) * XROW + jc) * 32 + h * 16;  // byte offset of this lane's B operand, tap (0,0), group 0
   const int wlane = j * 32 + h * 16;                         // byte offset of this lane's A operand, tap 0, cot 0
 
   auto compute = [&](int buf) {
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
 #pragma unroll
         for (int c = 0; c < COT; ++c) a[c] = *(const f32x4*)(ws + (tap * COT + c) * 1024);
 #pragma unroll
-        for (int r = 0; r < PT; ++r) b[r] = *(const f32x4*)(xs + ((r + dy) * XROW + dx) * 32);
+        for (int r = 0; r < PT; ++r) b[r] = *(const f32x4*)(xs + ((r * RPG + dy) * XROW + dx) * 32);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -178,12 +198,18 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: [old +] bias, LeakyReLU, residual scale-adds, optional accumulate / LReLU-backward mask
-  const int x = x0 + j;
+  const int x = x0 + jc;
   const long long HW = (long long)p.oH * p.oW;
   const int rx = x * p.dst_mul + p.dst_ox;
 #pragma unroll
   for (int r = 0; r < PT; ++r) {
-    const int y = y0 + wave * PT + r;
+    int y = y0 + (wave * PT + r) * RPG + jr;
+    int n = n_grid;
+    if (stacked) {
+      n = y / p.stack_hs;
+      y -= n * p.stack_hs;
+      if (n >= p.stack_n) continue;
+    }
     const int ry = y * p.dst_mul + p.dst_oy;
     if (y >= p.H || x >= p.W || ry >= p.oH || rx >= p.oW) continue;
     const long long pixoff = (long long)ry * p.oW + rx;
@@ -351,21 +377,22 @@ __global__ __launch_bounds__(256) void conv_fewcout_f32_kernel(const ConvParams 
   }
 }
 
-template <int COT, int PT, int KS, int NW = 4>
+template <int COT, int PT, int KS, int NW = 4, int WT = 32>
 constexpr int conv_lds_bytes() {
-  return 2 * ((((NW * PT + KS - 1) * (32 + KS - 1) * 32 + 1023) / 1024) * 1024 + KS * KS * COT * 1024);
+  return 2 * ((((NW * PT * (32 / WT) + KS - 1) * (WT + KS - 1) * 32 + 1023) / 1024) * 1024 + KS * KS * COT * 1024);
 }
 
-template <int COT, int PT, int KS, bool NCHW_OUT>
+template <int COT, int PT, int KS, bool NCHW_OUT, int WT = 32>
 int launch(const ConvParams& p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
-  constexpr int lds = conv_lds_bytes<COT, PT, KS>();
-  auto kern = conv_f32_kernel<COT, PT, KS, NCHW_OUT>;
+  constexpr int lds = conv_lds_bytes<COT, PT, KS, 4, WT>();
+  auto kern = conv_f32_kernel<COT, PT, KS, NCHW_OUT, 0, 4, WT>;
   if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   dim3 grid(p.tiles_x * p.tiles_y * n, groups);
   const bool prof = sr::prof_on();
   if (prof) {
     sr_launch_record r = {};
-    r.kernel_id = PT == 4 ? 13 : PT == 1 ? (COT == 1 ? 15 : 41) : (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
+    r.kernel_id = WT < 32 ? 44 + (KS == 2 ? 2 : 0) + (WT == 8 ? 1 : 0)
+                          : PT == 4 ? 13 : PT == 1 ? (COT == 1 ? 15 : 41) : (COT - 1) * 4 + (KS == 2 ? 2 : 0) + (NCHW_OUT ? 1 : 0);
     r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
     r.cout = d->cout;
     r.n = n;
@@ -453,6 +480,28 @@ int check_sizes(const ConvParams& p, int n, const char* who) {
   return SR_OK;
 }
 
+// Small feature maps (W <= 16: the 16x16 ... 4x4 layers of VGGStyleDiscriminator128, discriminator_arch.py:33-46): a
+// 32-pixel-wide tile would idle 50-88 % of its lanes and tiles could not be taller than one tiny image.  Narrow tiles
+// (WT = 16 / 8) over the vertically STACKED batch (ConvParams::stack_hs) fix both.  Returns -1 when not applicable.
+template <int KS>
+int launch_small(ConvParams q, const sr_conv3x3_desc* d, int groups, int gc, hipStream_t stream) {
+  if (gc != 64 || d->out_nchw || q.W > 16 || q.vH != q.H || q.vW != q.W) return -1;
+  if ((long long)d->n * q.in_ns + (long long)q.in_h * q.in_w * 8 >= (1ll << 31)) return -1;
+  q.stack_hs = q.H + 1;
+  q.stack_n = d->n;
+  const long long vrows = (long long)d->n * q.stack_hs;
+  if (q.W > 8) {
+    q.tiles_x = sr::cdiv(q.W, 16);
+    const bool big = vrows / 16 * q.tiles_x * groups >= 128;  // 4 waves x PT x 2 rows per tile
+    q.tiles_y = (int)sr::cdiv((int)vrows, big ? 16 : 8);
+    return big ? launch<2, 2, KS, false, 16>(q, 1, groups, stream, d) : launch<2, 1, KS, false, 16>(q, 1, groups, stream, d);
+  }
+  q.tiles_x = sr::cdiv(q.W, 8);
+  const bool big = vrows / 32 * q.tiles_x * groups >= 128;  // 4 waves x PT x 4 rows per tile
+  q.tiles_y = (int)sr::cdiv((int)vrows, big ? 32 : 16);
+  return big ? launch<2, 2, KS, false, 8>(q, 1, groups, stream, d) : launch<2, 1, KS, false, 8>(q, 1, groups, stream, d);
+}
+
 }  // namespace
 
 extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
@@ -501,6 +550,7 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   // Small inputs (single plate crops, 32x32 training patches): with 8-row tiles the launch has fewer workgroups than the
   // chip has CUs and every layer is a serial walk over K on a few CUs; 4-row tiles double the workgroups (more halo and
   // weight refill per MFMA, irrelevant while CUs idle).
+  if (int rs = launch_small<3>(p, d, groups, gc, stream); rs >= 0) return rs;
   if ((long long)p.tiles_x * p.tiles_y * d->n * groups < 256 && p.H > 4) {
     p.tiles_y = sr::cdiv(p.H, 4);
     return gc == 64 ? launch<2, 1, 3, false>(p, d->n, groups, stream, d) : launch<1, 1, 3, false>(p, d->n, groups, stream, d);
@@ -555,7 +605,8 @@ extern "C" int sr_conv4x4s2_f32(const sr_conv3x3_desc* d, void* stream_) {
       q.alpha = 1.f;
       q.res1 = q.res2 = nullptr;
     }
-    rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
+    rc = launch_small<2>(q, d, groups, gc, stream);
+    if (rc < 0) rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
     if (rc) return rc;
   }
   return SR_OK;
@@ -595,7 +646,8 @@ extern "C" int sr_conv4x4s2_dgrad_f32(const sr_conv3x3_desc* d, void* stream_) {
     q.tap_ox = px ? 0 : -1;
     rc = check_sizes(q, d->n, "sr_conv4x4s2_dgrad_f32");
     if (rc) return rc;
-    rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
+    rc = launch_small<2>(q, d, groups, gc, stream);
+    if (rc < 0) rc = gc == 64 ? launch<2, PT, 2, false>(q, d->n, groups, stream, d) : launch<1, PT, 2, false>(q, d->n, groups, stream, d);
     if (rc) return rc;
   }
   return SR_OK;
@@ -628,6 +680,11 @@ extern "C" const char* sr_kernel_name(int id) {
                                     "wgrad_bf16_kernelILi2ELi2ELi2ELi2ELi3E", "wgrad_bf16_kernelILi2ELi4ELi1ELi1ELi4E",
                                     "wgrad_bf16_kernelILi1ELi3ELi2ELi1ELi4E", "wgrad_bf16_kernelILi1ELi5ELi1ELi1ELi4E"};
     return gnames[id - 32];
+  }
+  if (id >= 44 && id < 48) {  // small-map variants: WT 16 / 8, KS 3 / 2 (PT 1 or 2 share an id)
+    static const char* snames[4] = {"conv_f32_kernel<2,*,3,false,0,4,16>", "conv_f32_kernel<2,*,3,false,0,4,8>", "conv_f32_kernel<2,*,2,false,0,4,16>",
+                                    "conv_f32_kernel<2,*,2,false,0,4,8>"};
+    return snames[id - 44];
   }
   if (id == 40) return "wgrad_rdb_bf16_kernel";
   if (id == 42) return "conv_bf16_kernelILi1ELi1ELi4ELb0E";
