@@ -1,50 +1,46 @@
 """name -> class registries, the plugin seam of the path.
 
-Mirrors the behaviour of the reference's ``basicsr/utils/registry.py`` (Registry :4-75,
-the five global registries :78-82): ``register()`` works as decorator or call, a
-duplicate name asserts, ``get()`` of an unknown name raises ``KeyError``.
+Same observable behaviour as the reference's ``basicsr/utils/registry.py`` (Registry :4-75, the five global
+registries :78-82): ``@REG.register()`` or ``REG.register(obj)`` files an object under its ``__name__``, filing a
+name twice asserts, looking up an unknown name raises ``KeyError``.
 """
 
 
 class Registry:
+    """A named table of classes / functions keyed by their ``__name__``."""
 
     def __init__(self, name):
-        self._name = name
-        self._obj_map = {}
+        self.name = name
+        self.table = {}
 
-    def _do_register(self, name, obj):
-        assert name not in self._obj_map, (f"An object named '{name}' was already registered "
-                                           f"in '{self._name}' registry!")
-        self._obj_map[name] = obj
+    def _file(self, obj):
+        key = obj.__name__
+        assert key not in self.table, f"An object named '{key}' was already registered in '{self.name}' registry!"
+        self.table[key] = obj
+        return obj
 
     def register(self, obj=None):
+        # decorator form returns the filing function itself (it hands the object back); call form files right away
         if obj is None:
-
-            def deco(func_or_class):
-                self._do_register(func_or_class.__name__, func_or_class)
-                return func_or_class
-
-            return deco
-        self._do_register(obj.__name__, obj)
+            return self._file
+        self._file(obj)
+        return None
 
     def get(self, name):
-        ret = self._obj_map.get(name)
-        if ret is None:
-            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
-        return ret
+        try:
+            return self.table[name]
+        except KeyError:
+            raise KeyError(f"No object named '{name}' found in '{self.name}' registry!") from None
 
     def __contains__(self, name):
-        return name in self._obj_map
+        return name in self.table
 
     def __iter__(self):
-        return iter(self._obj_map.items())
+        return iter(self.table.items())
 
     def keys(self):
-        return self._obj_map.keys()
+        return self.table.keys()
 
 
-DATASET_REGISTRY = Registry('dataset')
-ARCH_REGISTRY = Registry('arch')
-MODEL_REGISTRY = Registry('model')
-LOSS_REGISTRY = Registry('loss')
-METRIC_REGISTRY = Registry('metric')
+ARCH_REGISTRY, MODEL_REGISTRY, LOSS_REGISTRY, DATASET_REGISTRY, METRIC_REGISTRY = (
+    Registry(kind) for kind in ('arch', 'model', 'loss', 'dataset', 'metric'))
