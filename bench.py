@@ -9,6 +9,10 @@ in HBM.  Prints ONE JSON line on rank 0.
 
 Multi-GPU: images are independent, so ranks shard the tiles with no data-path collective (weak
 scaling: 16 tiles per GPU); the only collectives are the timing barrier and the max over ranks.
+
+Secondary lines (never the judged metric): --dtype bf16 (reduced-precision kernels) and --mode train (whole ESRGAN
+training steps, BASELINE configs 2-3; with N ranks the model's data-parallel path all-reduces the gradient arenas
+over RCCL).
 """
 import argparse
 import ctypes as C
@@ -110,6 +114,64 @@ def kernel_rooflines(net, x):
     return out
 
 
+def train_mode(args, world, rank, dev, dist, backend):
+    """Secondary line: images/sec of whole ESRGANModel.optimize_parameters steps (generator forward/backward,
+    discriminator passes, losses, both fused Adam steps, EMA) on synthetic batches resident in HBM; with N ranks the model's
+    own data-parallel path runs (one RCCL all-reduce of each gradient arena per step) and per-GPU work is fixed (weak)."""
+    from image_restoration_amd.models import build_model
+    from image_restoration_amd.utils import synth
+    from image_restoration_amd.utils.options import parse
+    opt = parse(os.path.join(ROOT, 'training_config', 'train_rrdbnet_esrgan_x4_mi355x.yml'), ROOT, is_train=True)
+    opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = world > 1, rank, world, 1
+    opt['network_g']['compute_dtype'] = args.dtype
+    if args.disc == 'unet':
+        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True)
+    elif args.lq != 32:
+        raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
+    model = build_model(opt)
+    lq = torch.from_numpy(synth.uniform_input(100 + rank, (args.batch, 3, args.lq, args.lq))).to(dev)
+    gt = torch.from_numpy(synth.uniform_input(200 + rank, (args.batch, 3, 4 * args.lq, 4 * args.lq))).to(dev)
+
+    def step(i):
+        model.update_learning_rate(i, warmup_iter=-1)
+        model.feed_data({'lq': lq, 'gt': gt})
+        model.optimize_parameters(i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(1, args.warmup + 1):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup + 1, args.warmup + 1 + args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    log = model.get_current_log()
+    assert all(v == v and abs(v) < 1e30 for v in log.values()), log
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (ESRGAN training step: 23-block RRDBNet + %s, L1 + relativistic GAN loss, Adam, EMA)' % opt['network_d']['type'],
+            'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16 generator, f32 discriminator/optimiser',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
+                                   % (args.batch, args.lq, args.lq), 'global_batch': world * args.batch,
+                       'parallelism': 'dp%d, one all-reduce of each gradient arena per step' % world},
+            'losses': {k: float(v) for k, v in log.items()}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,6 +181,12 @@ def main():
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help="fp32 = the BASELINE metric (default, the judged line); bf16 = secondary reduced-precision run")
     ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning)')
+    ap.add_argument('--mode', choices=('infer', 'train'), default='infer',
+                    help='infer = the BASELINE metric (default, the judged line); train = secondary line: full ESRGAN '
+                         'optimize_parameters steps (BASELINE configs 3-4), data-parallel over the ranks')
+    ap.add_argument('--batch', type=int, default=32, help='--mode train: batch per GPU')
+    ap.add_argument('--lq', type=int, default=32, help='--mode train: LR patch size (gt = 4x)')
+    ap.add_argument('--disc', choices=('vgg', 'unet'), default='vgg', help='--mode train: discriminator')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -138,6 +206,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    if args.mode == 'train':
+        return train_mode(args, world, rank, dev, dist, backend)
 
     import image_restoration_amd as ira
     from image_restoration_amd.utils import synth
