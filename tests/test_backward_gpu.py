@@ -30,6 +30,8 @@ def _rel_l2(a, b):
     (64, 32, 64, 0, 12, 12, False), (96, 32, 64, 32, 9, 33, False), (128, 32, 64, 32, 16, 32, False),
     (160, 32, 64, 32, 7, 40, False), (192, 64, 64, 32, 10, 37, False), (64, 64, 64, 0, 5, 7, True),
     (64, 3, 64, 0, 17, 35, False), (3, 64, 3, 0, 6, 6, False), (44, 20, 20, 12, 11, 13, False),
+    # wide layers of the discriminators: many tile groups in one launch (grid.y) and one slab reduction, incl. odd tiles
+    (512, 512, 512, 0, 8, 8, False), (288, 160, 288, 0, 6, 10, False), (256, 96, 256, 0, 12, 12, False),
 ])
 def test_wgrad_kernel(cuda, cin, cout, first, seg, h, w, ups):
     n = 2

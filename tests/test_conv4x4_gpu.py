@@ -21,7 +21,9 @@ def _rel(a, b):
                                                 (128, 256, 16, 70, False), (16, 32, 10, 6, True), (3, 20, 12, 14, True),
                                                 # small maps -> narrow tiles over the stacked batch (conv_f32.hip: launch_small)
                                                 (64, 64, 32, 32, True), (64, 128, 16, 16, False), (128, 64, 8, 8, True),
-                                                (64, 64, 20, 24, False), (64, 64, 4, 4, True)])
+                                                (64, 64, 20, 24, False), (64, 64, 4, 4, True),
+                                                # wide: 16 x 16 tile groups per parity pass in one launch
+                                                (512, 512, 8, 8, False), (160, 288, 8, 12, True)])
 def test_conv4x4s2_fwd_dgrad_wgrad(cuda, cin, cout, h, w, bias):
     n = 5 if w <= 32 else 2
     rng = np.random.default_rng(cin * 7 + cout)
