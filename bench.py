@@ -125,7 +125,8 @@ def train_mode(args, world, rank, dev, dist, backend):
     opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = world > 1, rank, world, 1
     opt['network_g']['compute_dtype'] = args.dtype
     if args.disc == 'unet':
-        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True)
+        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True,
+                                compute_dtype=args.dtype)
     elif args.lq != 32:
         raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
     model = build_model(opt)
@@ -161,7 +162,9 @@ def train_mode(args, world, rank, dev, dist, backend):
             'metric': 'images/sec (ESRGAN training step: 23-block RRDBNet + %s, L1 + relativistic GAN loss, Adam, EMA)' % opt['network_d']['type'],
             'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16 generator, f32 discriminator/optimiser',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'fp32' else ('bf16 generator and discriminator, f32 master weights/optimiser' if args.disc == 'unet'
+                                                         else 'bf16 generator, f32 discriminator/optimiser'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
                                    % (args.batch, args.lq, args.lq), 'global_batch': world * args.batch,

@@ -133,6 +133,14 @@ SIGNATURES = {
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_cb16_axpby_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
+    'sr_cb16_unshuffle2_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
+    'sr_conv4x4s2_weight_as_3x3_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sr_lrelu_bwd_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    'sr_bilinear2x_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
+    'sr_bilinear2x_bwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
     'sr_rrdbnet_packed_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_workspace_bytes_bf16': (C.c_size_t, [C.POINTER(RRDBNetCfg), C.c_int, C.c_int, C.c_int]),
     'sr_rrdbnet_pack_bf16': (C.c_int, [C.POINTER(RRDBNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),

@@ -48,10 +48,16 @@ class UNetDiscriminatorSN(nn.Module):
     """UNetDiscriminatorSN(num_in_ch, num_feat=64, skip_connection=True): [N, C, H, W] -> [N, 1, H, W] logits
     (H, W multiples of 8)."""
 
-    def __init__(self, num_in_ch, num_feat=64, skip_connection=True):
+    def __init__(self, num_in_ch, num_feat=64, skip_connection=True, compute_dtype='fp32'):
         super().__init__()
         nf = num_feat
         self.num_in_ch, self.num_feat, self.skip_connection = num_in_ch, nf, skip_connection
+        if compute_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        # 'bf16': activations / activation gradients in CB16 bf16 on the generator's bf16 kernels (num_feat % 16 == 0);
+        # weights, spectral normalisation, weight gradients and the optimiser stay fp32
+        self.compute_dtype = compute_dtype
+        assert compute_dtype == 'fp32' or nf % 16 == 0, 'bf16 needs num_feat to be a multiple of 16'
         self.conv0 = Conv3x3Params(num_in_ch, nf, bias=True)
         self.conv1 = SNConvParams(nf, nf * 2, 4)
         self.conv2 = SNConvParams(nf * 2, nf * 4, 4)
@@ -67,6 +73,8 @@ class UNetDiscriminatorSN(nn.Module):
         if not x.is_cuda:
             raise _lib.SrHipError('UNetDiscriminatorSN.forward runs only on a HIP device (no CPU fallback)')
         assert x.size(2) % 8 == 0 and x.size(3) % 8 == 0, f'input {tuple(x.shape)} must be a multiple of 8 in H and W'
+        if self.compute_dtype == 'bf16':
+            return self._forward_bf16(x)
         conv = A.ConvFn.apply
         x0 = conv(A.ToCB8.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
         x1 = conv(x0, self.conv1.weight(), None, 0.2)
@@ -88,3 +96,28 @@ class UNetDiscriminatorSN(nn.Module):
         out = conv(out, self.conv8.weight(), None, 0.2)
         out = conv(out, self.conv9.weight, self.conv9.bias, 1.0)
         return A.FromCB8.apply(out, 1)
+
+    def _forward_bf16(self, x):
+        from .. import hip_autograd_bf16 as B
+
+        def conv(t, w, b, slope, nchw=False):
+            return B.ConvFn16.apply(t, w, b, slope, nchw)
+        x0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
+        x1 = conv(x0, self.conv1.weight(), None, 0.2)
+        x2 = conv(x1, self.conv2.weight(), None, 0.2)
+        x3 = conv(x2, self.conv3.weight(), None, 0.2)
+        x3 = B.Bilinear2xFn16.apply(x3)
+        x4 = conv(x3, self.conv4.weight(), None, 0.2)
+        if self.skip_connection:
+            x4 = B.AddFn16.apply(x4, x2)
+        x4 = B.Bilinear2xFn16.apply(x4)
+        x5 = conv(x4, self.conv5.weight(), None, 0.2)
+        if self.skip_connection:
+            x5 = B.AddFn16.apply(x5, x1)
+        x5 = B.Bilinear2xFn16.apply(x5)
+        x6 = conv(x5, self.conv6.weight(), None, 0.2)
+        if self.skip_connection:
+            x6 = B.AddFn16.apply(x6, x0)
+        out = conv(x6, self.conv7.weight(), None, 0.2)
+        out = conv(out, self.conv8.weight(), None, 0.2)
+        return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True)  # fp32 NCHW logits

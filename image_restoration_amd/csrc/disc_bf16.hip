@@ -1,0 +1,202 @@
+// Discriminator-side helpers of the bf16 path (UNetDiscriminatorSN with compute_dtype='bf16'; the reference contains no
+// reduced precision and no U-Net discriminator — SURVEY.md §0 D2/D5 — so everything here is a build extension whose
+// parity is declared against this library's fp32 path, tests/test_unet_disc_bf16_gpu.py).
+//
+// The 3x3 convolutions, their data and weight gradients are the generator's bf16 kernels (conv_bf16.hip,
+// wgrad_bf16.hip).  The 4x4 / stride-2 / pad-1 convolutions reuse them too: with X' = pixel_unshuffle(X, 2) in
+// parity-major channel order c' = (2 ry + rx) C + c,
+//     Y[oy][ox] = sum_{ky,kx} W[ky][kx] X[2 oy + ky - 1][2 ox + kx - 1]
+// is a 3x3 / stride-1 / pad-1 convolution of X' with W'[co][(2 ry + rx) C + c][ty][tx] = W[co][c][ky][kx] where
+// ky -> (ty, ry) = 0 -> (0,1), 1 -> (1,0), 2 -> (1,1), 3 -> (2,0) (same for kx) and all other entries zero: 16 of the
+// 36 taps are live, a 2.25x MAC overhead that is free at bf16 rates (these layers are memory-bound), against four
+// accumulating parity passes with bf16 rounding in between.
+#include "sr_internal.h"
+
+namespace {
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+// CB16 [N][C/16][2h][2w][16] -> CB16 [N][4C/16][h][w][16], channel c' = (2 ry + rx) C + c (C % 16 == 0);
+// one thread per destination half pixel-block.  inverse = 1 runs the adjoint (pixel_shuffle of that channel order).
+__global__ void unshuffle2_kernel(const __bf16* __restrict__ src, long long src_ns, __bf16* __restrict__ dst, long long dst_ns,
+                                  int cblocks, int h, int w, int inverse, long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int x = (int)(r % w);
+  r /= w;
+  const int y = (int)(r % h);
+  r /= h;
+  const int cb4 = (int)(r % (4 * cblocks)), n = (int)(r / (4 * cblocks));  // block of the 4C-channel tensor
+  const int par = cb4 / cblocks, cb = cb4 - par * cblocks;
+  const int ry = par >> 1, rx = par & 1;
+  const long long big = n * (inverse ? dst_ns : src_ns) + (((long long)cb * 2 * h + 2 * y + ry) * (2 * w) + 2 * x + rx) * 16 + half * 8;
+  const long long small = n * (inverse ? src_ns : dst_ns) + (((long long)cb4 * h + y) * w + x) * 16 + half * 8;
+  if (inverse)
+    *(bf16x8_t*)(dst + big) = *(const bf16x8_t*)(src + small);
+  else
+    *(bf16x8_t*)(dst + small) = *(const bf16x8_t*)(src + big);
+}
+
+// dz = gy * (y > 0 ? 1 : slope), 8 elements per thread
+__global__ void lrelu_bwd16_kernel(const __bf16* __restrict__ gy, const __bf16* __restrict__ y, __bf16* __restrict__ dz, float slope,
+                                   long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8_t g = ((const bf16x8_t*)gy)[i], a = ((const bf16x8_t*)y)[i];
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (float)a[e] > 0.f ? g[e] : (__bf16)((float)g[e] * slope);
+  ((bf16x8_t*)dz)[i] = o;
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), see train_ops.hip
+__device__ __forceinline__ void bil_taps16(int o, int size, int& i0, int& i1, float& w0, float& w1) {
+  float s = (o + 0.5f) * 0.5f - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < size - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+  w0 = 1.f - w1;
+}
+__global__ void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long long src_ns, __bf16* __restrict__ dst, long long dst_ns,
+                                        int cblocks, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int W2 = 2 * w, H2 = 2 * h;
+  const int ox = (int)(r % W2);
+  r /= W2;
+  const int oy = (int)(r % H2);
+  r /= H2;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  int y0, y1, x0, x1;
+  float wy0, wy1, wx0, wx1;
+  bil_taps16(oy, h, y0, y1, wy0, wy1);
+  bil_taps16(ox, w, x0, x1, wx0, wx1);
+  const __bf16* b = src + n * src_ns + (long long)cb * h * w * 16 + half * 8;
+  const bf16x8_t a00 = *(const bf16x8_t*)(b + ((long long)y0 * w + x0) * 16), a01 = *(const bf16x8_t*)(b + ((long long)y0 * w + x1) * 16),
+                 a10 = *(const bf16x8_t*)(b + ((long long)y1 * w + x0) * 16), a11 = *(const bf16x8_t*)(b + ((long long)y1 * w + x1) * 16);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    o[e] = (__bf16)(wy0 * (wx0 * (float)a00[e] + wx1 * (float)a01[e]) + wy1 * (wx0 * (float)a10[e] + wx1 * (float)a11[e]));
+  *(bf16x8_t*)(dst + n * dst_ns + (((long long)cb * H2 + oy) * W2 + ox) * 16 + half * 8) = o;
+}
+// gsrc[y][x] = sum over the (at most 4x4) outputs whose taps touch (y, x): a gather, deterministic
+__global__ void bilinear2x_bwd16_kernel(const __bf16* __restrict__ g, long long g_ns, __bf16* __restrict__ gsrc, long long gsrc_ns,
+                                        int cblocks, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int x = (int)(r % w);
+  r /= w;
+  const int y = (int)(r % h);
+  r /= h;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const int W2 = 2 * w, H2 = 2 * h;
+  const __bf16* b = g + n * g_ns + (long long)cb * H2 * W2 * 16 + half * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int oy = 2 * y - 1; oy <= 2 * y + 2; ++oy) {
+    if (oy < 0 || oy >= H2) continue;
+    int y0, y1;
+    float wy0, wy1;
+    bil_taps16(oy, h, y0, y1, wy0, wy1);
+    const float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = 2 * x - 1; ox <= 2 * x + 2; ++ox) {
+      if (ox < 0 || ox >= W2) continue;
+      int x0, x1;
+      float wx0, wx1;
+      bil_taps16(ox, w, x0, x1, wx0, wx1);
+      const float wgt = wy * ((x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f));
+      if (wgt == 0.f) continue;
+      const bf16x8_t v = *(const bf16x8_t*)(b + ((long long)oy * W2 + ox) * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
+    }
+  }
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+  *(bf16x8_t*)(gsrc + n * gsrc_ns + (((long long)cb * h + y) * w + x) * 16 + half * 8) = o;
+}
+
+// W [cout][cin][4][4] <-> W' [cout][4 cin][3][3] (see the header comment); thread per (co, c, ky, kx)
+__device__ __forceinline__ void k4_to_t3(int k, int& t, int& r) {
+  t = (k + 1) >> 1;   // 0 -> 0, 1 -> 1, 2 -> 1, 3 -> 2
+  r = (k + 1) & 1;    // 0 -> 1, 1 -> 0, 2 -> 1, 3 -> 0
+}
+__global__ void w4_to_w3_kernel(const float* __restrict__ w4, float* __restrict__ w3, int cout, int cin, int adjoint) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * cin * 16) return;
+  const int kx = i & 3, ky = (i >> 2) & 3, c = (i >> 4) % cin, co = i / (16 * cin);
+  int ty, ry, tx, rx;
+  k4_to_t3(ky, ty, ry);
+  k4_to_t3(kx, tx, rx);
+  const long long j = (((long long)co * 4 * cin + (2 * ry + rx) * cin + c) * 3 + ty) * 3 + tx;
+  if (adjoint)
+    ((float*)w4)[i] = w3[j];  // gradient fold-back: dW[co][c][ky][kx] = dW'[...]
+  else
+    w3[j] = w4[i];
+}
+}  // namespace
+
+extern "C" int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, void* dst, int64_t dst_img_stride, int n,
+                                       int cblocks, int h, int w, int inverse, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(src && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_unshuffle2_bf16: bad argument");
+  const long long total = (long long)n * 4 * cblocks * h * w * 2;
+  hipLaunchKernelGGL(unshuffle2_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_img_stride,
+                     (__bf16*)dst, (long long)dst_img_stride, cblocks, h, w, inverse, total);
+  SR_CHECK_LAUNCH("cb16_unshuffle2");
+  return SR_OK;
+}
+
+extern "C" int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float slope, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(gy && y && dz && n > 0 && n % 8 == 0, "sr_lrelu_bwd_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(lrelu_bwd16_kernel, dim3(nblk(n / 8)), dim3(256), 0, stream, (const __bf16*)gy, (const __bf16*)y, (__bf16*)dz,
+                     slope, (long long)(n / 8));
+  SR_CHECK_LAUNCH("lrelu_bwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_ns, void* dst, int64_t dst_ns, int n, int cblocks, int h, int w,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(src && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_fwd_bf16: bad argument");
+  const long long total = (long long)n * cblocks * 2 * h * 2 * w * 2;
+  hipLaunchKernelGGL(bilinear2x_fwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_ns,
+                     (__bf16*)dst, (long long)dst_ns, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("bilinear2x_fwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_ns, void* gsrc, int64_t gsrc_ns, int n, int cblocks, int h, int w,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g && gsrc && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_bwd_bf16: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 2;
+  hipLaunchKernelGGL(bilinear2x_bwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g, (long long)g_ns,
+                     (__bf16*)gsrc, (long long)gsrc_ns, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("bilinear2x_bwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_conv4x4s2_weight_as_3x3_f32(float* w4, float* w3, int cout, int cin, int adjoint, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(w4 && w3 && cout > 0 && cin > 0, "sr_conv4x4s2_weight_as_3x3_f32: bad argument");
+  if (!adjoint && hipMemsetAsync(w3, 0, (size_t)cout * 4 * cin * 9 * sizeof(float), stream) != hipSuccess) {
+    sr::set_error("sr_conv4x4s2_weight_as_3x3_f32: memset failed");
+    return SR_ELAUNCH;
+  }
+  const int total = cout * cin * 16;
+  hipLaunchKernelGGL(w4_to_w3_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w4, w3, cout, cin, adjoint);
+  SR_CHECK_LAUNCH("w4_to_w3");
+  return SR_OK;
+}

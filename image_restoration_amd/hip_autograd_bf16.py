@@ -1,0 +1,183 @@
+"""torch.autograd.Function wrappers of the bf16 single-op C ABI (discriminator with compute_dtype='bf16').
+
+Activations travel between these Functions as torch.bfloat16 tensors shaped [N, C/16, H, W, 16] (the CB16 layout of
+include/sr_hip.h); weights, biases and their gradients stay fp32 (the master copies the optimiser updates); every
+forward / backward below is libsr_hip.so launches only.  Twin of hip_autograd.py (fp32, CB8).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import hip_ops as H
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _cb16(t):
+    return H.CB16(t)
+
+
+class ToCB16(torch.autograd.Function):
+    """NCHW fp32 -> CB16 bf16 (sr_nchw_to_cb16_bf16); backward CB16 -> NCHW fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.c = x.size(1)
+        return H.nchw_to_cb16(x).buf
+
+    @staticmethod
+    def backward(ctx, g):
+        return H.cb16_to_nchw(_cb16(g.contiguous()), ctx.c)
+
+
+def _unshuffle2(t, inverse=False):
+    """CB16 [N, C/16, 2h, 2w, 16] <-> [N, 4C/16, h, w, 16] (parity-major channels) — sr_cb16_unshuffle2_bf16."""
+    lib = _lib.load()
+    n, cb, hh, ww, _ = t.shape
+    if inverse:
+        cblocks, h, w = cb // 4, hh, ww
+        out = torch.empty((n, cblocks, 2 * h, 2 * w, 16), dtype=torch.bfloat16, device=t.device)
+    else:
+        cblocks, h, w = cb, hh // 2, ww // 2
+        out = torch.empty((n, 4 * cblocks, h, w, 16), dtype=torch.bfloat16, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(lib.sr_cb16_unshuffle2_bf16(t.data_ptr(), t[0].numel(), out.data_ptr(), out[0].numel(), n, cblocks, h, w,
+                                               int(inverse), _stream(t.device)), 'sr_cb16_unshuffle2_bf16')
+    return out
+
+
+def _w4_as_w3(w4):
+    lib = _lib.load()
+    cout, cin = w4.shape[:2]
+    w3 = torch.empty((cout, 4 * cin, 3, 3), dtype=torch.float32, device=w4.device)
+    with torch.cuda.device(w4.device):
+        _lib.check(lib.sr_conv4x4s2_weight_as_3x3_f32(w4.data_ptr(), w3.data_ptr(), cout, cin, 0, _stream(w4.device)),
+                   'sr_conv4x4s2_weight_as_3x3_f32')
+    return w3
+
+
+def _dw3_to_dw4(dw3, cout, cin):
+    lib = _lib.load()
+    dw4 = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=dw3.device)
+    with torch.cuda.device(dw3.device):
+        _lib.check(lib.sr_conv4x4s2_weight_as_3x3_f32(dw4.data_ptr(), dw3.data_ptr(), cout, cin, 1, _stream(dw3.device)),
+                   'sr_conv4x4s2_weight_as_3x3_f32')
+    return dw4
+
+
+class ConvFn16(torch.autograd.Function):
+    """3x3/s1/p1 or 4x4/s2/p1 convolution (+bias, +LeakyReLU(act_slope)) on CB16 with fp32 master weights.
+
+    forward  : sr_conv3x3_bf16; a 4x4/s2 conv = the same kernel on the pixel-unshuffled input with the 3x3-embedded
+               weights (csrc/disc_bf16.hip).  out_nchw=True returns fp32 NCHW (the logit map of the last layer).
+    backward : sr_lrelu_bwd_bf16, data gradient = sr_conv3x3_bf16 with the transposed image (+ pixel shuffle back for 4x4),
+               weight gradient = sr_conv3x3_wgrad_bf16 in fp32 (folded back to 4x4).
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act_slope, out_nchw):
+        k = weight.size(2)
+        weight = weight.detach().contiguous().float()
+        cout, cin = weight.shape[:2]
+        if k == 4:
+            src = _cb16(_unshuffle2(x.contiguous()))
+            w3 = _w4_as_w3(weight)
+        elif k == 3:
+            src, w3 = _cb16(x.contiguous()), weight
+        else:
+            raise NotImplementedError(f'kernel size {k}')
+        pc = H.PackedConvBF16(w3, bias)
+        if out_nchw:
+            assert act_slope == 1.0
+            y = torch.empty((src.n, cout, src.h, src.w), dtype=torch.float32, device=x.device)
+            H.conv3x3_bf16(src, pc, out_nchw=y)
+            saved_y = None
+            ret = y
+        else:
+            out = H.conv3x3_bf16(src, pc, act_slope=act_slope)
+            saved_y = out.buf if act_slope != 1.0 else None
+            ret = out.buf
+        ctx.save_for_backward(src.buf, w3, saved_y)
+        ctx.act_slope, ctx.has_bias, ctx.k, ctx.out_nchw = act_slope, bias is not None, k, out_nchw
+        ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xs, w3, y = ctx.saved_tensors
+        src = _cb16(xs)
+        dev = gy.device
+        cout, cin3 = w3.shape[:2]
+        if ctx.out_nchw:
+            dzc = H.nchw_to_cb16(gy.contiguous().float())
+        else:
+            gy = gy.contiguous()
+            if y is not None:
+                dz = torch.empty_like(gy)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.sr_lrelu_bwd_bf16(gy.data_ptr(), y.data_ptr(), dz.data_ptr(), ctx.act_slope, gy.numel(),
+                                                     _stream(dev)), 'sr_lrelu_bwd_bf16')
+            else:
+                dz = gy
+            dzc = _cb16(dz)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_x:
+            d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1)).buf  # roundup16(cin3) channels
+            dx = _unshuffle2(d, inverse=True) if ctx.k == 4 else d
+            if dx.size(1) != ctx.x_cb:
+                dx = dx[:, :ctx.x_cb].contiguous()
+        if need_w or (need_b and ctx.has_bias):
+            dw, db = H.conv3x3_wgrad_bf16(src, dzc, cout, cin3, want_bias=ctx.has_bias)
+            if ctx.k == 4:
+                dw = _dw3_to_dw4(dw, ctx.cout, ctx.cin)
+        return dx, dw, (db if ctx.has_bias else None), None, None
+
+
+class Bilinear2xFn16(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB16 (sr_bilinear2x_{fwd,bwd}_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, cb, h, w, _ = x.shape
+        y = torch.empty((n, cb, 2 * h, 2 * w, 16), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_bilinear2x_fwd_bf16(x.data_ptr(), x[0].numel(), y.data_ptr(), y[0].numel(), n, cb, h, w,
+                                                  _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = g.contiguous()
+        n, cb, h2, w2, _ = g.shape
+        gx = torch.empty((n, cb, h2 // 2, w2 // 2, 16), dtype=torch.bfloat16, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.sr_bilinear2x_bwd_bf16(g.data_ptr(), g[0].numel(), gx.data_ptr(), gx[0].numel(), n, cb, h2 // 2, w2 // 2,
+                                                  _stream(g.device)), 'sr_bilinear2x_bwd_bf16')
+        return gx
+
+
+class AddFn16(torch.autograd.Function):
+    """a + b on CB16 (skip connections): a copy of a, then sr_cb16_axpby_bf16."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        out = a.clone()
+        b = b.contiguous()
+        n, cb, h, w, _ = out.shape
+        with torch.cuda.device(a.device):
+            _lib.check(lib.sr_cb16_axpby_bf16(out.data_ptr(), out[0].numel(), b.data_ptr(), b[0].numel(), 1.0, 1.0, n, cb, h, w,
+                                              _stream(a.device)), 'sr_cb16_axpby_bf16')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

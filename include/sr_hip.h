@@ -330,6 +330,21 @@ int sr_upsample2x_bwd_bf16(const void* g, int64_t g_img_stride, void* dst, int64
                            int64_t mask_img_stride, float mask_slope, int n, int cblocks, int h, int w, void* stream);
 int sr_cb16_axpby_bf16(void* dst, int64_t dst_img_stride, const void* src, int64_t src_img_stride, float a, float b, int n,
                        int cblocks, int h, int w, void* stream);
+/* Discriminator-side helpers of the bf16 path (disc_bf16.hip; UNetDiscriminatorSN with compute_dtype = 'bf16').
+ * A 4x4 / stride-2 / pad-1 convolution runs as a 3x3 convolution of the pixel-unshuffled input:
+ *   sr_cb16_unshuffle2_bf16: [N][C/16][2h][2w][16] -> [N][4C/16][h][w][16], channel (2 ry + rx) C + c (C % 16 == 0;
+ *                            cblocks = C/16; inverse = 1 is the adjoint, i.e. the data gradient's way back);
+ *   sr_conv4x4s2_weight_as_3x3_f32: W[cout][cin][4][4] -> W'[cout][4 cin][3][3] (16 live taps of 36, the rest zero);
+ *                            adjoint = 1 folds a 3x3 weight gradient back into w4.
+ * sr_lrelu_bwd_bf16 / sr_bilinear2x_{fwd,bwd}_bf16 are the CB16 twins of the fp32 entry points above. */
+int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, void* dst, int64_t dst_img_stride, int n, int cblocks,
+                            int h, int w, int inverse, void* stream);
+int sr_conv4x4s2_weight_as_3x3_f32(float* w4, float* w3, int cout, int cin, int adjoint, void* stream);
+int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float slope, int64_t n, void* stream);
+int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, void* dst, int64_t dst_img_stride, int n, int cblocks, int h,
+                           int w, void* stream);
+int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, int n, int cblocks, int h,
+                           int w, void* stream);
 size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg);
 size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
 int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream);

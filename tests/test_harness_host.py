@@ -35,6 +35,7 @@ def test_sampler_matches_reference_streams(golden):
     ('options/train/ESRGAN/train_RRDBNet_PSNR_x4_synthetic.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16.yml', True),
+    ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml', True),
     ('options/test/ESRGAN/test_ESRGAN_x4_woGT.yml', False),
 ])
 def test_option_files_parse_like_the_reference(path, is_train, tmp_path):

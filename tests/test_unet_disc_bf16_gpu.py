@@ -1,0 +1,103 @@
+"""UNetDiscriminatorSN with compute_dtype='bf16' (an extension of an extension: the reference has neither the U-Net
+discriminator nor reduced precision).  Op tests compare with float64 computations of the same
+bf16-rounded operands (what is tested is the kernel, not the quantisation); the whole network is compared with this
+library's fp32 path on the same weights, tolerances stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import image_restoration_amd as ira
+from image_restoration_amd import hip_autograd_bf16 as B
+from image_restoration_amd import hip_ops as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def test_unshuffle_roundtrip_and_order(cuda):
+    x = torch.randn(2, 32, 12, 20)
+    t = H.nchw_to_cb16(x.to(cuda)).buf
+    u = B._unshuffle2(t)
+    assert tuple(u.shape) == (2, 8, 6, 10, 16)
+    got = H.cb16_to_nchw(H.CB16(u), 128).cpu().double()
+    xb = _bf(x)
+    for ry in range(2):
+        for rx in range(2):
+            par = 2 * ry + rx
+            assert torch.equal(got[:, par * 32:(par + 1) * 32], xb[:, :, ry::2, rx::2])
+    assert torch.equal(B._unshuffle2(u, inverse=True), t)
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(16, 32, 2, 16, 24), (64, 128, 2, 32, 32), (128, 64, 1, 8, 16)])
+def test_conv4x4s2_as_unshuffled_3x3(cuda, cin, cout, n, h, w):
+    """Forward, data gradient and weight gradient of the 4x4/s2/p1 conv through ConvFn16 vs float64 autograd of the
+    rounded operands: outputs / dx to one bf16 ulp (2^-8 relative + 1e-3 abs), dW to 2e-3 of its max (dz is rounded to bf16
+    before the weight gradient, as in every bf16 backward here)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    gy = torch.randn(n, cout, h // 2, w // 2, generator=g)
+    xr, wr = _bf(x).requires_grad_(True), _bf(wt).requires_grad_(True)
+    pre = F.conv2d(xr, wr, None, 2, 1)
+    y = F.leaky_relu(pre, 0.2)
+    y.backward(_bf(gy))
+    xc = H.nchw_to_cb16(x.to(cuda)).buf.requires_grad_(True)
+    wc = wt.to(cuda).requires_grad_(True)
+    yc = B.ConvFn16.apply(xc, wc, None, 0.2, False)
+    got = H.cb16_to_nchw(H.CB16(yc.detach()), cout).cpu().double()
+    assert torch.all((got - y.detach()).abs() <= y.detach().abs() * 2 ** -8 + 1e-3)
+    yc.backward(H.nchw_to_cb16(gy.to(cuda)).buf)
+    dx = H.cb16_to_nchw(H.CB16(xc.grad), cin).cpu().double()
+    assert float((dx - xr.grad).abs().max()) <= 2 ** -7 * float(xr.grad.abs().max()) + 1e-3
+    assert float((wc.grad.cpu().double() - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
+
+
+def test_bilinear2x_bf16(cuda):
+    x = torch.randn(2, 32, 6, 10)
+    xr = _bf(x).requires_grad_(True)
+    y = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False)
+    g = torch.randn(2, 32, 12, 20)
+    y.backward(_bf(g))
+    xc = H.nchw_to_cb16(x.to(cuda)).buf.requires_grad_(True)
+    yc = B.Bilinear2xFn16.apply(xc)
+    got = H.cb16_to_nchw(H.CB16(yc.detach()), 32).cpu().double()
+    assert torch.all((got - y.detach()).abs() <= y.detach().abs() * 2 ** -8 + 1e-6)
+    yc.backward(H.nchw_to_cb16(g.to(cuda)).buf)
+    dx = H.cb16_to_nchw(H.CB16(xc.grad), 32).cpu().double()
+    assert torch.all((dx - xr.grad).abs() <= xr.grad.abs() * 2 ** -8 + 1e-6)
+
+
+@pytest.mark.parametrize('nf,h,w', [(16, 32, 48), (64, 64, 64)])
+def test_unet_bf16_vs_fp32_path(cuda, nf, h, w):
+    """Logits and parameter gradients of the bf16 network against the fp32 HIP network (itself checked against the oracle in
+    tests/test_unet_disc_gpu.py) on the same weights: logits within 3 % of their range, every gradient within relative-L2
+    8e-2 and cosine >= 0.995 (10 layers of bf16 activations and activation gradients)."""
+    torch.manual_seed(7)
+    d32 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=True)).to(cuda).train()
+    d16 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=True,
+                                 compute_dtype='bf16')).to(cuda).train()
+    d16.load_state_dict(d32.state_dict())
+    x = torch.rand(2, 3, h, w, device=cuda)
+    tgt = torch.rand(2, 1, h, w, device=cuda)
+    outs, grads = {}, {}
+    for name, net in (('fp32', d32), ('bf16', d16)):
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        F.binary_cross_entropy_with_logits(y, tgt).backward()  # loss on the fp32 logits: plain torch, not the path under test
+        outs[name] = y.detach()
+        grads[name] = [xi.grad] + [p.grad for p in net.parameters()]
+    assert outs['bf16'].dtype == torch.float32 and outs['bf16'].shape == outs['fp32'].shape
+    rng = float(outs['fp32'].max() - outs['fp32'].min())
+    assert float((outs['bf16'] - outs['fp32']).abs().max()) <= 3e-2 * rng
+    names = ['x'] + [k for k, _ in d32.named_parameters()]
+    for name, a, b in zip(names, grads['fp32'], grads['bf16']):
+        assert torch.isfinite(b).all(), name
+        rel = float((a - b).norm() / (a.norm() + 1e-20))
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-20))
+        assert rel <= 8e-2 and cos >= 0.995, (name, rel, cos)
+    # power-iteration buffers advanced identically (spectral norm stays fp32)
+    assert torch.allclose(d16.conv3.weight_u, d32.conv3.weight_u, atol=1e-6)
