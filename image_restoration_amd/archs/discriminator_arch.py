@@ -31,10 +31,15 @@ class BatchNormParams(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def apply_lrelu(self, x, slope):
-        """BatchNorm (batch statistics in train mode, running statistics in eval mode) + LeakyReLU on CB8."""
+    def apply_lrelu(self, x, slope, bf16=False):
+        """BatchNorm (batch statistics in train mode, running statistics in eval mode) + LeakyReLU on CB8 (or, bf16=True,
+        on CB16 bf16 activations with fp32 parameters and statistics)."""
         if self.training:
             self.num_batches_tracked += 1
+        if bf16:
+            from ..hip_autograd_bf16 import BNLReLUFn16
+            return BNLReLUFn16.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                     self.momentum, self.eps, slope)
         return A.BNLReLUFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                  self.momentum, self.eps, slope)
 
@@ -62,10 +67,16 @@ class LinearParams(nn.Module):
 class VGGStyleDiscriminator128(nn.Module):
     """VGGStyleDiscriminator128(num_in_ch, num_feat): [N, num_in_ch, 128, 128] -> [N, 1] logits."""
 
-    def __init__(self, num_in_ch, num_feat):
+    def __init__(self, num_in_ch, num_feat, compute_dtype='fp32'):
         super().__init__()
         nf = num_feat
         self.num_in_ch, self.num_feat = num_in_ch, num_feat
+        if compute_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        # option key beyond the reference's: 'bf16' = CB16 bf16 activations / activation gradients on the generator's bf16
+        # kernels (num_feat % 16 == 0); weights, BatchNorm statistics, weight gradients, linear layers and optimiser stay fp32
+        assert compute_dtype == 'fp32' or nf % 16 == 0, 'bf16 needs num_feat to be a multiple of 16'
+        self.compute_dtype = compute_dtype
         self.conv0_0 = Conv3x3Params(num_in_ch, nf, bias=True)
         self.conv0_1 = Conv3x3Params(nf, nf, bias=False, ksize=4)
         self.bn0_1 = BatchNormParams(nf)
@@ -82,6 +93,8 @@ class VGGStyleDiscriminator128(nn.Module):
         assert x.size(2) == 128 and x.size(3) == 128, (f'Input spatial size must be 128x128, but received {x.size()}.')
         if not x.is_cuda:
             raise _lib.SrHipError('VGGStyleDiscriminator128.forward runs only on a HIP device (no CPU fallback)')
+        if self.compute_dtype == 'bf16':
+            return self._forward_bf16(x)
         feat = A.ToCB8.apply(x.contiguous().float())
         feat = A.ConvFn.apply(feat, self.conv0_0.weight, self.conv0_0.bias, 0.2)            # lrelu(conv0_0(x))
         feat = self.bn0_1.apply_lrelu(A.ConvFn.apply(feat, self.conv0_1.weight, None, 1.0), 0.2)  # 64x64
@@ -92,5 +105,20 @@ class VGGStyleDiscriminator128(nn.Module):
             feat = b1.apply_lrelu(A.ConvFn.apply(feat, c1.weight, None, 1.0), 0.2)           # 32, 16, 8, 4
         feat = A.FromCB8.apply(feat, self.num_feat * 8)
         feat = feat.reshape(feat.size(0), -1)                                                # view(N, -1): plain metadata
+        feat = A.LinearFn.apply(feat, self.linear1.weight, self.linear1.bias, 0.2)
+        return A.LinearFn.apply(feat, self.linear2.weight, self.linear2.bias, 1.0)
+
+    def _forward_bf16(self, x):
+        from .. import hip_autograd_bf16 as B
+
+        def conv(t, p, slope):
+            return B.ConvFn16.apply(t, p.weight, p.bias, slope, False)
+        feat = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0_0, 0.2)                # lrelu(conv0_0(x))
+        feat = self.bn0_1.apply_lrelu(conv(feat, self.conv0_1, 1.0), 0.2, bf16=True)           # 64x64
+        for i in range(1, 5):
+            feat = getattr(self, f'bn{i}_0').apply_lrelu(conv(feat, getattr(self, f'conv{i}_0'), 1.0), 0.2, bf16=True)
+            feat = getattr(self, f'bn{i}_1').apply_lrelu(conv(feat, getattr(self, f'conv{i}_1'), 1.0), 0.2, bf16=True)
+        feat = B.FromCB16.apply(feat, self.num_feat * 8)                                        # fp32 NCHW for the linear head
+        feat = feat.reshape(feat.size(0), -1)
         feat = A.LinearFn.apply(feat, self.linear1.weight, self.linear1.bias, 0.2)
         return A.LinearFn.apply(feat, self.linear2.weight, self.linear2.bias, 1.0)

@@ -200,3 +200,227 @@ extern "C" int sr_conv4x4s2_weight_as_3x3_f32(float* w4, float* w3, int cout, in
   SR_CHECK_LAUNCH("w4_to_w3");
   return SR_OK;
 }
+
+// ------------------------------------------------------------------ BatchNorm (+LeakyReLU) on CB16
+// nn.BatchNorm2d of VGGStyleDiscriminator128 (discriminator_arch.py:23-49) on bf16 activations: statistics, running
+// buffers, gamma / beta and their gradients are fp32; two-pass statistics with fixed-order two-stage reductions
+// (train_ops.hip, the fp32 twin).  Workspace >= sr_reduce_workspace_bytes(c).
+namespace {
+constexpr int RED16 = 64;  // blocks per reduced quantity (== train_ops.hip RED_SPLITS)
+
+__device__ __forceinline__ float block_sum16(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+struct BnRed16 {
+  const __bf16* x;
+  const __bf16* dy;
+  const __bf16* y;
+  const float* mean;
+  const float* invstd;
+  float* part;  // [cblocks16][RED16][16][2]
+  long long x_ns, dy_ns, y_ns;
+  int n, hw, mode;  // 0: sum x ; 1: sum (x-mean)^2 ; 2: sum dz, sum dz*xhat
+  float slope;
+};
+// grid (cblocks16, RED16), block 256: thread t covers 8 channels (half = t & 1) of pixels t>>1, t>>1 + 128, ...
+__global__ __launch_bounds__(256) void bn_reduce16_kernel(const BnRed16 p) {
+  __shared__ float sh[4];
+  const int cb = blockIdx.x, sp = blockIdx.y;
+  const int half = threadIdx.x & 1;
+  const long long total = (long long)p.n * p.hw;
+  float a[8], b[8], mu[8], is[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = b[e] = 0.f;
+    mu[e] = p.mode >= 1 ? p.mean[cb * 16 + half * 8 + e] : 0.f;
+    is[e] = p.mode == 2 ? p.invstd[cb * 16 + half * 8 + e] : 1.f;
+  }
+  for (long long i = (long long)sp * 128 + (threadIdx.x >> 1); i < total; i += 128 * RED16) {
+    const int n = (int)(i / p.hw);
+    const long long off = ((long long)cb * p.hw + (i - (long long)n * p.hw)) * 16 + half * 8;
+    const bf16x8_t xv = *(const bf16x8_t*)(p.x + n * p.x_ns + off);
+    if (p.mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)xv[e];
+    } else if (p.mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += ((float)xv[e] - mu[e]) * ((float)xv[e] - mu[e]);
+    } else {
+      const bf16x8_t gv = *(const bf16x8_t*)(p.dy + n * p.dy_ns + off), yv = *(const bf16x8_t*)(p.y + n * p.y_ns + off);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = (float)yv[e] > 0.f ? (float)gv[e] : (float)gv[e] * p.slope;
+        a[e] += dz;
+        b[e] += dz * ((float)xv[e] - mu[e]) * is[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float s0 = block_sum16(half == 0 ? a[e] : 0.f, sh), s1 = block_sum16(half == 1 ? a[e] : 0.f, sh);
+    const float t0 = block_sum16(half == 0 ? b[e] : 0.f, sh), t1 = block_sum16(half == 1 ? b[e] : 0.f, sh);
+    if (threadIdx.x == 0) {
+      float* o = p.part + (((long long)cb * RED16 + sp) * 16) * 2;
+      o[e * 2] = s0;
+      o[e * 2 + 1] = t0;
+      o[(8 + e) * 2] = s1;
+      o[(8 + e) * 2 + 1] = t1;
+    }
+  }
+}
+// one thread per channel.  which 0: mean ; 1: var -> invstd (+ running stats) ; 2: dbeta / dgamma
+__global__ void bn_finalize16_kernel(const float* part, int c, int which, long long count, float eps, float momentum, float* mean,
+                                     float* invstd, float* running_mean, float* running_var, float* dgamma, float* dbeta) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const int cb = ch >> 4, e = ch & 15;
+  float s = 0.f, t = 0.f;
+  for (int k = 0; k < RED16; ++k) {
+    const float* o = part + (((long long)cb * RED16 + k) * 16 + e) * 2;
+    s += o[0];
+    t += o[1];
+  }
+  if (which == 0) {
+    mean[ch] = s / (float)count;
+  } else if (which == 1) {
+    const float var = s / (float)count;
+    invstd[ch] = rsqrtf(var + eps);
+    if (running_mean) {  // nn.BatchNorm2d: running = (1-m)*running + m*batch, with the UNBIASED variance
+      const float unbiased = count > 1 ? s / (float)(count - 1) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean[ch];
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+  } else {
+    dbeta[ch] = s;
+    dgamma[ch] = t;
+  }
+}
+__global__ void bn_eval_prep16_kernel(const float* rm, const float* rv, float eps, int c, float* mean, float* invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) {
+    mean[ch] = rm[ch];
+    invstd[ch] = rsqrtf(rv[ch] + eps);
+  }
+}
+// fwd: y = lrelu((x - mean)*invstd*gamma + beta) ; bwd: dx = gamma*invstd*(dz - [train] (dbeta + xhat*dgamma)/M)
+__global__ void bn_lrelu16_kernel(const __bf16* __restrict__ x, long long x_ns, const __bf16* __restrict__ dy, long long dy_ns,
+                                  const __bf16* __restrict__ yin, long long yin_ns, __bf16* __restrict__ out, long long out_ns,
+                                  const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                  float slope, int backward, int train, float inv_count, int c, int cblocks, int hw, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int pix = (int)(r % hw);
+  r /= hw;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const long long off = ((long long)cb * hw + pix) * 16 + half * 8;
+  const bf16x8_t xv = *(const bf16x8_t*)(x + n * x_ns + off);
+  bf16x8_t gv, yv, o;
+  if (backward) {
+    gv = *(const bf16x8_t*)(dy + n * dy_ns + off);
+    yv = *(const bf16x8_t*)(yin + n * yin_ns + off);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cb * 16 + half * 8 + e;
+    float v = 0.f;
+    if (ch < c) {
+      const float xhat = ((float)xv[e] - mean[ch]) * invstd[ch];
+      if (!backward) {
+        v = xhat * gamma[ch] + beta[ch];
+        v = v > 0.f ? v : v * slope;
+      } else {
+        const float dz = (float)yv[e] > 0.f ? (float)gv[e] : (float)gv[e] * slope;
+        v = train ? gamma[ch] * invstd[ch] * (dz - (dbeta[ch] + xhat * dgamma[ch]) * inv_count) : gamma[ch] * invstd[ch] * dz;
+      }
+    }
+    o[e] = (__bf16)v;
+  }
+  *(bf16x8_t*)(out + n * out_ns + off) = o;
+}
+}  // namespace
+
+extern "C" int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_ns, void* y, int64_t y_ns, int n, int c, int h, int w, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, int train, float momentum,
+                                    float eps, float slope, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && ws && n > 0 && c > 0 && h > 0 && w > 0,
+               "sr_bn_lrelu_fwd_bf16: bad argument");
+  SR_CHECK_ARG(train || (running_mean && running_var), "sr_bn_lrelu_fwd_bf16: eval mode needs running statistics");
+  SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_fwd_bf16: workspace too small");
+  const int cblocks = (c + 15) / 16, hw = h * w;
+  const long long count = (long long)n * hw;
+  float* part = (float*)ws;
+  if (train) {
+    BnRed16 p = {};
+    p.x = (const __bf16*)x;
+    p.x_ns = x_ns;
+    p.n = n;
+    p.hw = hw;
+    p.part = part;
+    p.mode = 0;
+    hipLaunchKernelGGL(bn_reduce16_kernel, dim3(cblocks, RED16), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_finalize16_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 0, count, eps, momentum, save_mean,
+                       save_invstd, nullptr, nullptr, nullptr, nullptr);
+    p.mode = 1;
+    p.mean = save_mean;
+    hipLaunchKernelGGL(bn_reduce16_kernel, dim3(cblocks, RED16), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_finalize16_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 1, count, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var, nullptr, nullptr);
+  } else {
+    hipLaunchKernelGGL(bn_eval_prep16_kernel, dim3(nblk(c)), dim3(256), 0, stream, running_mean, running_var, eps, c, save_mean,
+                       save_invstd);
+  }
+  const long long total = (long long)n * cblocks * hw * 2;
+  hipLaunchKernelGGL(bn_lrelu16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)x, (long long)x_ns, nullptr, 0ll,
+                     nullptr, 0ll, (__bf16*)y, (long long)y_ns, save_mean, save_invstd, gamma, beta, nullptr, nullptr, slope, 0, train,
+                     0.f, c, cblocks, hw, total);
+  SR_CHECK_LAUNCH("bn_lrelu_fwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_bn_lrelu_bwd_bf16(const void* x, int64_t x_ns, const void* dy, int64_t dy_ns, const void* y, int64_t y_ns, void* dx,
+                                    int64_t dx_ns, int n, int c, int h, int w, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, int train, float slope, float* dgamma, float* dbeta, void* ws,
+                                    size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && dy && y && dx && gamma && save_mean && save_invstd && dgamma && dbeta && ws && n > 0 && c > 0,
+               "sr_bn_lrelu_bwd_bf16: bad argument");
+  SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_bwd_bf16: workspace too small");
+  const int cblocks = (c + 15) / 16, hw = h * w;
+  const long long count = (long long)n * hw;
+  float* part = (float*)ws;
+  BnRed16 p = {};
+  p.x = (const __bf16*)x;
+  p.x_ns = x_ns;
+  p.dy = (const __bf16*)dy;
+  p.dy_ns = dy_ns;
+  p.y = (const __bf16*)y;
+  p.y_ns = y_ns;
+  p.mean = save_mean;
+  p.invstd = save_invstd;
+  p.n = n;
+  p.hw = hw;
+  p.part = part;
+  p.mode = 2;
+  p.slope = slope;
+  hipLaunchKernelGGL(bn_reduce16_kernel, dim3(cblocks, RED16), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(bn_finalize16_kernel, dim3(nblk(c)), dim3(256), 0, stream, part, c, 2, count, 0.f, 0.f, nullptr, nullptr, nullptr,
+                     nullptr, dgamma, dbeta);
+  const long long total = (long long)n * cblocks * hw * 2;
+  hipLaunchKernelGGL(bn_lrelu16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)x, (long long)x_ns, (const __bf16*)dy,
+                     (long long)dy_ns, (const __bf16*)y, (long long)y_ns, (__bf16*)dx, (long long)dx_ns, save_mean, save_invstd, gamma,
+                     nullptr, dgamma, dbeta, slope, 1, train, 1.f / (float)count, c, cblocks, hw, total);
+  SR_CHECK_LAUNCH("bn_lrelu_bwd16");
+  return SR_OK;
+}

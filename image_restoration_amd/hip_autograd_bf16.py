@@ -181,3 +181,67 @@ class AddFn16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+class FromCB16(torch.autograd.Function):
+    """CB16 bf16 -> NCHW fp32 with `channels` real channels; backward NCHW fp32 -> CB16 (pad channels zero)."""
+
+    @staticmethod
+    def forward(ctx, t, channels):
+        ctx.cb = t.size(1)
+        return H.cb16_to_nchw(_cb16(t.contiguous()), channels)
+
+    @staticmethod
+    def backward(ctx, g):
+        out = H.nchw_to_cb16(g.contiguous().float())
+        assert out.buf.size(1) == ctx.cb
+        return out.buf, None
+
+
+class BNLReLUFn16(torch.autograd.Function):
+    """nn.BatchNorm2d + LeakyReLU on CB16 (sr_bn_lrelu_fwd_bf16 / sr_bn_lrelu_bwd_bf16); parameters, statistics and running
+    buffers fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, train, momentum, eps, slope):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, cb, h, w, _ = x.shape
+        c = gamma.numel()
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        wsb = lib.sr_reduce_workspace_bytes(c)
+        ws = H.scratch(dev, wsb)
+        ns = cb * h * w * 16
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_bn_lrelu_fwd_bf16(x.data_ptr(), ns, y.data_ptr(), ns, n, c, h, w, gamma.data_ptr(), beta.data_ptr(),
+                                                running_mean.data_ptr() if running_mean is not None else None,
+                                                running_var.data_ptr() if running_var is not None else None, int(train), momentum,
+                                                eps, slope, mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), wsb, _stream(dev)),
+                       'sr_bn_lrelu_fwd_bf16')
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.train, ctx.slope = bool(train), slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        n, cb, h, w, _ = x.shape
+        c = gamma.numel()
+        dev = x.device
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        wsb = lib.sr_reduce_workspace_bytes(c)
+        ws = H.scratch(dev, wsb)
+        ns = cb * h * w * 16
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_bn_lrelu_bwd_bf16(x.data_ptr(), ns, gy.data_ptr(), ns, y.data_ptr(), ns, dx.data_ptr(), ns, n, c, h, w,
+                                                gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), int(ctx.train), ctx.slope,
+                                                dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), wsb, _stream(dev)),
+                       'sr_bn_lrelu_bwd_bf16')
+        return dx, dgamma, dbeta, None, None, None, None, None, None

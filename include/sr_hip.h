@@ -345,6 +345,16 @@ int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, void* dst, i
                            int w, void* stream);
 int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, int n, int cblocks, int h,
                            int w, void* stream);
+/* nn.BatchNorm2d + LeakyReLU of VGGStyleDiscriminator128 on CB16 activations (bf16 in / out; statistics, running
+ * buffers, gamma / beta and their gradients fp32): twins of sr_bn_lrelu_{fwd,bwd}_f32, same arguments. */
+int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_img_stride, void* y, int64_t y_img_stride, int n, int c, int h, int w,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, int train,
+                         float momentum, float eps, float slope, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                         void* stream);
+int sr_bn_lrelu_bwd_bf16(const void* x, int64_t x_img_stride, const void* dy, int64_t dy_img_stride, const void* y,
+                         int64_t y_img_stride, void* dx, int64_t dx_img_stride, int n, int c, int h, int w, const float* gamma,
+                         const float* save_mean, const float* save_invstd, int train, float slope, float* dgamma, float* dbeta,
+                         void* ws, size_t ws_bytes, void* stream);
 size_t sr_rrdbnet_packed_bytes_bf16(const sr_rrdbnet_cfg* cfg);
 size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w);
 int sr_rrdbnet_pack_bf16(const sr_rrdbnet_cfg* cfg, const float* const* host_params, void* packed, void* stream);
