@@ -40,6 +40,7 @@ struct WgradParamsH {
   int cin_blocks;    // valid 16-channel blocks of x
   int cout_blocks;   // valid 16-channel blocks of dy
   int cin_tile0, cout_tile0;
+  int gi;            // cin groups per cout-group row: blockIdx.y = (row, column) of a grid of same-shaped tile groups
   int strips, rows_per_wg, row_splits;
   int src_shift;     // 1: x is read through the nearest x2 upsample
   long long* dbg;    // development: per-wave phase clocks (sr_dev_wgrad_bf16_phase_clocks)
@@ -101,6 +102,8 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = wave / (IT * KS), it = (wave / KS) % IT, ks = wave % KS;
+  const int grow = blockIdx.y / p.gi, gcol = blockIdx.y - grow * p.gi;  // several tile groups per launch (grid.y)
+  const int cout_tile0 = p.cout_tile0 + grow * CT, cin_tile0 = p.cin_tile0 + gcol * IT;
 
   int t = blockIdx.x;
   const int rs = t % p.row_splits;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
     const int q = v * 64 + lane;
     const int plane = q / PLP, within = q - plane * PLP;
     const int px = within >> 1, half = within & 1;
-    const int cb = p.cin_tile0 * 2 + plane;
+    const int cb = cin_tile0 * 2 + plane;
     const int gx = x0 - 1 + px;
     const bool ok = plane < IT * 2 && px < 66 && vy >= 0 && vy < p.H && gx >= 0 && gx < p.W && cb < p.cin_blocks;
     const int sy = vy >> p.src_shift, sx = gx >> p.src_shift;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
     const int q = v * 64 + lane;
     const int plane = q / PLP, within = q - plane * PLP;
     const int px = within >> 1, half = within & 1;
-    const int cb = p.cout_tile0 * 2 + plane;
+    const int cb = cout_tile0 * 2 + plane;
     const int gx = x0 + px;
     // rows at or below y_end belong to the next workgroup: they arrive as zeros, so the k-steps need no row guard
     // (a guard around the MFMAs makes hipcc copy all 144 accumulator registers twice per step)
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
   if (ks == 0) {
     // this pair's tile:  slab[workgroup][pair][tap][g][lane][4]
     const int pair = ct * IT + it;
-    float* dst = p.slab + (((long long)blockIdx.x * P + pair) * 9) * 1024 + lane * 4;
+    float* dst = p.slab + ((((long long)blockIdx.y * gridDim.x + blockIdx.x) * P + pair) * 9) * 1024 + lane * 4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -287,14 +290,14 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
         for (int e = 0; e < 4; ++e) v[e] = acc[tap][g * 4 + e];
         *(f32x4*)(dst + tap * 1024 + g * 256) = v;
       }
-    if (p.bslab && it == 0) {
+    if (p.bslab && it == 0 && gcol == 0) {
       // lane (blk, li, kh) summed cout blk*16 + li over its kh half of the pixels
       bsum += __shfl_xor(bsum, 32);
-      if (kh == 0) p.bslab[((long long)blockIdx.x * CT + ct) * 32 + blk * 16 + li] = bsum;
+      if (kh == 0) p.bslab[(((long long)grow * gridDim.x + blockIdx.x) * CT + ct) * 32 + blk * 16 + li] = bsum;
     }
   }
   if (p.dbg && lane == 0) {
-    long long* o = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+    long long* o = p.dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
     o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_readcyclecounter() - tk[0]; o[5] = nsteps;
   }
 }
@@ -579,24 +582,27 @@ SlabCarve carve_slab(void* base, size_t bytes) {
 }
 
 template <int CT, int IT, int KS, int R, int NSTG>
-int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, const SlabCarve& sc,
-                 bool want_bias, hipStream_t stream) {
+int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, int grows, int gi,
+                 const SlabCarve& sc, bool want_bias, hipStream_t stream) {
   using G = WgradGeom<CT, IT, KS, R, NSTG>;
   constexpr int P = G::P;
   constexpr int lds = G::LDS;
   static_assert(lds <= 160 * 1024, "rings do not fit the LDS");
+  const int groups = grows * gi;  // same-shaped tile groups of this launch (grid.y), one slab reduction for all
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
-  // one workgroup per CU: every workgroup leaves P fp32 tiles of 36 KB, so more workgroups = more slab traffic
+  p.gi = gi;
+  // about one workgroup per CU over the whole launch: every workgroup leaves P fp32 tiles of 36 KB
   const long long strips_total = (long long)d->n * p.strips;
-  const int want = (int)(256 / strips_total) > 1 ? (int)(256 / strips_total) : 1;
+  const int want = (int)(256 / (strips_total * groups)) > 1 ? (int)(256 / (strips_total * groups)) : 1;
   int rows = sr::cdiv(p.H, want);
   rows = (rows + R - 1) / R * R;
   p.rows_per_wg = rows;
   p.row_splits = sr::cdiv(p.H, rows);
   const long long nwg = strips_total * p.row_splits;
-  if ((size_t)nwg * P * 9 * 1024 * sizeof(float) > sc.wslab_bytes || (size_t)nwg * CT * 32 * sizeof(float) > sc.wslab_bytes / 64) {
-    sr::set_error("sr_conv3x3_wgrad_bf16: slab too small (need %zu B of tiles)", (size_t)nwg * P * 9 * 1024 * sizeof(float));
+  if ((size_t)groups * nwg * P * 9 * 1024 * sizeof(float) > sc.wslab_bytes ||
+      (size_t)grows * nwg * CT * 32 * sizeof(float) > sc.wslab_bytes / 64) {
+    sr::set_error("sr_conv3x3_wgrad_bf16: slab too small (need %zu B of tiles)", (size_t)groups * nwg * P * 9 * 1024 * sizeof(float));
     return SR_ENOSPACE;
   }
   p.slab = sc.slab;
@@ -615,11 +621,11 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
     r.w = p.W;
     const double px = (double)d->n * p.H * p.W;
     const int cin_eff = min(32 * IT, d->cin_pad - 32 * cin_tile0), cout_eff = min(32 * CT, d->cout - 32 * cout_tile0);
-    r.flops = 2.0 * 9 * cin_eff * cout_eff * px;
-    r.bytes = 2.0 * px * (cin_eff + cout_eff) + 2.0 * nwg * P * 9 * 4096;
+    r.flops = 2.0 * 9 * cin_eff * cout_eff * px * groups;
+    r.bytes = (2.0 * px * (cin_eff + cout_eff) + 2.0 * nwg * P * 9 * 4096) * groups;
     sr::prof_begin(stream, r);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(G::NW * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)groups), dim3(G::NW * 64), lds, stream, p);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("wgrad_bf16 launch");
   sr::WgradReduce rr = {};
@@ -628,6 +634,8 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
   rr.part = sc.part;
   rr.bpart = sc.bpart;
   rr.splits = nwg;
+  rr.groups = groups;
+  rr.gi = gi;
   rr.P = P;
   rr.IT = IT;
   rr.CT = CT;
@@ -899,41 +907,72 @@ extern "C" int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* strea
   p.strips = sr::cdiv(p.W, 64);
   const SlabCarve sc = carve_slab(d->slab, d->slab_bytes);
   SR_CHECK_ARG(sc.wslab_bytes > 0, "sr_conv3x3_wgrad_bf16: slab too small");
-  // walk the (cout tile, cin tile) grid in workgroup-sized groups
+  // walk the (cout tile, cin tile) grid in workgroup-sized groups; the 2 x 4 groups of wide layers (the discriminators'
+  // 512-channel convs: up to 64 of them) go out as one launch per chunk of cout rows with one slab reduction
   const int cts = sr::cdiv(d->cout, 32), its = sr::cdiv(cin_pad, 32);
+  const long long strips_total = (long long)d->n * p.strips;
   for (int c0 = 0; c0 < cts;) {
     const int cn = (cts - c0 >= 2) ? 2 : 1;
-    for (int i0 = 0; i0 < its;) {
+    int i0 = 0;
+    if (cn == 2 && its >= 4 && its / 4 <= 32) {
+      const int gi = its / 4, rows_left = (cts - c0) / 2;
+      // slab: groups * workgroups tiles of 8 pairs; partial buffers: groups * 8 pairs <= 256 and rows * 2 * 32 bias floats
+      long long cap = (long long)(sc.wslab_bytes / ((size_t)8 * 9 * 1024 * sizeof(float))) / (strips_total > 0 ? strips_total : 1);
+      long long rows = cap / gi;
+      if (rows > 32 / gi) rows = 32 / gi;
+      if (rows < 1) rows = 1;
+      if (rows > rows_left) rows = rows_left;
+      int rc = launch_group<2, 4, 1, 1, 4>(d, p, c0, 0, (int)rows, gi, sc, d->dbias != nullptr, stream);
+      if (rc) return rc;
+      i0 = gi * 4;
+      // the remaining cin tiles of these rows, row by row
+      for (int r = 0; r < rows; ++r) {
+        int j0 = i0;
+        while (j0 < its) {
+          const int left = its - j0;
+          int in, rc2;
+          if (left >= 2) {
+            in = 2;
+            rc2 = launch_group<2, 2, 2, 2, 3>(d, p, c0 + 2 * r, j0, 1, 1, sc, false, stream);
+          } else {
+            in = 1;
+            rc2 = launch_group<2, 1, 4, 2, 4>(d, p, c0 + 2 * r, j0, 1, 1, sc, false, stream);
+          }
+          if (rc2) return rc2;
+          j0 += in;
+        }
+      }
+      c0 += 2 * (int)rows;
+      continue;
+    }
+    for (; i0 < its;) {
       const int left = its - i0;
       const bool bias = d->dbias != nullptr && i0 == 0;
       int rc, in;
       if (cn == 2) {
-        if (left >= 4) {
-          in = 4;
-          rc = launch_group<2, 4, 1, 1, 4>(d, p, c0, i0, sc, bias, stream);
-        } else if (left >= 2) {
+        if (left >= 2) {
           in = 2;
-          rc = launch_group<2, 2, 2, 2, 3>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<2, 2, 2, 2, 3>(d, p, c0, i0, 1, 1, sc, bias, stream);
         } else {
           in = 1;
-          rc = launch_group<2, 1, 4, 2, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<2, 1, 4, 2, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         }
       } else {
         if (left == 5 || left >= 9) {  // conv4 of a dense block: one 5-wave pass instead of 4 + 1
           in = 5;
-          rc = launch_group<1, 5, 1, 1, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<1, 5, 1, 1, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         } else if (left >= 4) {
           in = 4;
-          rc = launch_group<1, 4, 2, 1, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<1, 4, 2, 1, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         } else if (left == 3) {
           in = 3;
-          rc = launch_group<1, 3, 2, 1, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<1, 3, 2, 1, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         } else if (left == 2) {
           in = 2;
-          rc = launch_group<1, 2, 4, 2, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<1, 2, 4, 2, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         } else {
           in = 1;
-          rc = launch_group<1, 1, 8, 2, 4>(d, p, c0, i0, sc, bias, stream);
+          rc = launch_group<1, 1, 8, 2, 4>(d, p, c0, i0, 1, 1, sc, bias, stream);
         }
       }
       if (rc) return rc;

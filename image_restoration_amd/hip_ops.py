@@ -310,6 +310,10 @@ class CB16:
     def zeros(n, channels, h, w, device):
         return CB16(torch.zeros((n, (channels + 15) // 16, h, w, 16), dtype=torch.bfloat16, device=device))
 
+    @staticmethod
+    def empty(n, channels, h, w, device):
+        return CB16(torch.empty((n, (channels + 15) // 16, h, w, 16), dtype=torch.bfloat16, device=device))
+
     n = property(lambda s: s.buf.size(0))
     h = property(lambda s: s.buf.size(2))
     w = property(lambda s: s.buf.size(3))
@@ -333,7 +337,7 @@ def nchw_to_cb16(x, unshuffle=1):
     x = x.contiguous().float()
     n, c, sh, sw = x.shape
     h, w = sh // unshuffle, sw // unshuffle
-    out = CB16.zeros(n, c * unshuffle * unshuffle, h, w, x.device)
+    out = CB16.empty(n, c * unshuffle * unshuffle, h, w, x.device)  # the kernel writes every block, pad channels as zero
     with torch.cuda.device(x.device):
         _lib.check(lib.sr_nchw_to_cb16_bf16(x.data_ptr(), out.ptr, n, c, h, w, unshuffle, out.cbn, out.img_stride,
                                             _stream(x.device)), 'sr_nchw_to_cb16_bf16')
@@ -395,7 +399,7 @@ def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0,
         ret = out_nchw
     else:
         if out is None:
-            out = CB16.zeros(src.n, pc.cout, H, W, src.device)
+            out = CB16.empty(src.n, pc.cout, H, W, src.device)  # every valid block is written (pad couts: zero weights)
         assert (out.n, out.h, out.w) == (src.n, H, W) and out.channels >= (pc.cout + 15) // 16 * 16
         d.out, d.out_img_stride, d.out_nchw = out.ptr, out.img_stride, 0
         ret = out
