@@ -162,3 +162,32 @@ def test_vgg128_bf16_vs_fp32_path(cuda):
             assert rel <= 0.12 and cos >= 0.99, (k, rel, cos)
     assert torch.allclose(d16.bn4_1.running_var, d32.bn4_1.running_var, rtol=2e-2, atol=1e-4)
     assert int(d16.bn0_1.num_batches_tracked) == 1
+
+
+def test_c3_training_config_runs_all_bf16(cuda):
+    """training_config/train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml (BASELINE configs[2]: bf16 generator + bf16
+    UNetDiscriminatorSN) with the networks shrunk: three optimize_parameters iterations, finite losses of the right keys,
+    parameters actually move, EMA follows."""
+    import os
+    from image_restoration_amd.models import build_model
+    from image_restoration_amd.utils.options import parse
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opt = parse(os.path.join(root, 'training_config', 'train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml'), root, is_train=True)
+    opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = False, 0, 1, 1
+    assert opt['network_g']['compute_dtype'] == 'bf16' and opt['network_d']['compute_dtype'] == 'bf16'
+    opt['network_g'].update(num_feat=32, num_block=1, num_grow_ch=16)
+    opt['network_d']['num_feat'] = 16
+    model = build_model(opt)
+    assert model.net_g.compute_dtype == 'bf16' and model.net_d.compute_dtype == 'bf16'
+    w0 = model.net_g.conv_last.weight.detach().clone()
+    d0 = model.net_d.conv9.weight.detach().clone()
+    g = torch.Generator().manual_seed(0)
+    for it in range(1, 4):
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.feed_data({'lq': torch.rand(2, 3, 16, 24, generator=g), 'gt': torch.rand(2, 3, 64, 96, generator=g)})
+        model.optimize_parameters(it)
+        log = model.get_current_log()
+        assert set(log) == {'l_g_pix', 'l_g_gan', 'l_d_real', 'l_d_fake', 'out_d_real', 'out_d_fake'}
+        assert all(np.isfinite(v) for v in log.values()), log
+    assert not torch.equal(model.net_g.conv_last.weight, w0) and not torch.equal(model.net_d.conv9.weight, d0)
+    assert not torch.equal(model.net_g_ema.conv_last.weight, w0)
