@@ -525,6 +525,81 @@ __global__ __launch_bounds__(256) void ssim_sum_kernel(const float* __restrict__
   if (threadIdx.x == 0) part[(long long)n * gridDim.x + blockIdx.x] = s;
 }
 
+// ------------------------------------------------------------------ VGG feature extractor helpers (PerceptualLoss)
+// nn.MaxPool2d(kernel_size=2, stride=2) on CB8 (vgg_arch.py:131-137), floor mode; thread per output float4.
+__global__ void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int cblocks, int h, int w,
+                                      long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int oh = h / 2, ow = w / 2;
+  const int ox = (int)(r % ow);
+  r /= ow;
+  const int oy = (int)(r % oh);
+  const long long ncb = r / oh;  // n * cblocks + cb
+  const float* b = x + ((ncb * h + 2 * oy) * w + 2 * ox) * 8 + half * 4;
+  const float4 a00 = *(const float4*)b, a01 = *(const float4*)(b + 8), a10 = *(const float4*)(b + (long long)w * 8),
+               a11 = *(const float4*)(b + (long long)w * 8 + 8);
+  float4 o;
+  o.x = fmaxf(fmaxf(a00.x, a01.x), fmaxf(a10.x, a11.x));
+  o.y = fmaxf(fmaxf(a00.y, a01.y), fmaxf(a10.y, a11.y));
+  o.z = fmaxf(fmaxf(a00.z, a01.z), fmaxf(a10.z, a11.z));
+  o.w = fmaxf(fmaxf(a00.w, a01.w), fmaxf(a10.w, a11.w));
+  *(float4*)(y + ((ncb * oh + oy) * ow + ox) * 8 + half * 4) = o;
+}
+// dx: the gradient of a window goes to its first maximum in scan order (torch's choice); thread per INPUT float4
+__global__ void maxpool2x2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int cblocks,
+                                      int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int xx = (int)(r % w);
+  r /= w;
+  const int yy = (int)(r % h);
+  const long long ncb = r / h;
+  const int oh = h / 2, ow = w / 2;
+  const int oy = yy >> 1, ox = xx >> 1;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (oy < oh && ox < ow) {
+    const float* b = x + ((ncb * h + 2 * oy) * w + 2 * ox) * 8 + half * 4;
+    const float4 v[4] = {*(const float4*)b, *(const float4*)(b + 8), *(const float4*)(b + (long long)w * 8),
+                         *(const float4*)(b + (long long)w * 8 + 8)};
+    const float4 g = *(const float4*)(dy + ((ncb * oh + oy) * ow + ox) * 8 + half * 4);
+    const int me = (yy & 1) * 2 + (xx & 1);
+    const float* vf = (const float*)v;
+    const float gs[4] = {g.x, g.y, g.z, g.w};
+    float os[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int arg = 0;
+      float m = vf[e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (vf[k * 4 + e] > m) {
+          m = vf[k * 4 + e];
+          arg = k;
+        }
+      os[e] = arg == me ? gs[e] : 0.f;
+    }
+    o = make_float4(os[0], os[1], os[2], os[3]);
+  }
+  *(float4*)(dx + ((ncb * h + yy) * w + xx) * 8 + half * 4) = o;
+}
+// y[n][c][:] = x * a[c] + b[c] on NCHW (input normalisation, vgg_arch.py:156-159; its backward is the same with b = null)
+__global__ void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ a,
+                                      const float* __restrict__ b, int c, long long hw, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)((i / hw) % c);
+  y[i] = x[i] * a[ch] + (b ? b[ch] : 0.f);
+}
+__global__ void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] > 0.f ? x[i] : x[i] * slope;
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -825,5 +900,41 @@ extern "C" int sr_ssim_sum_f32(const float* a, const float* b, int n, int c, int
   hipLaunchKernelGGL(ssim_sum_kernel, dim3(parts, n), dim3(256), 0, stream, a, b, c, h, w, crop_border, win, (float*)ws);
   hipLaunchKernelGGL(psnr_finalize_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, parts, sum);
   SR_CHECK_LAUNCH("ssim_sum");
+  return SR_OK;
+}
+
+extern "C" int sr_maxpool2x2_fwd_f32(const float* x, float* y, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && n > 0 && cblocks > 0 && h >= 2 && w >= 2, "sr_maxpool2x2_fwd_f32: bad argument");
+  const long long total = (long long)n * cblocks * (h / 2) * (w / 2) * 2;
+  hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, x, y, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("maxpool2x2_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_maxpool2x2_bwd_f32(const float* x, const float* dy, float* dx, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && dy && dx && n > 0 && cblocks > 0 && h >= 2 && w >= 2, "sr_maxpool2x2_bwd_f32: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 2;
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, x, dy, dx, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("maxpool2x2_bwd");
+  return SR_OK;
+}
+
+extern "C" int sr_channel_affine_f32(const float* x, float* y, const float* a, const float* b, int n, int c, int64_t hw,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && a && n > 0 && c > 0 && hw > 0, "sr_channel_affine_f32: bad argument");
+  const long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(channel_affine_kernel, dim3(nblk(total)), dim3(256), 0, stream, x, y, a, b, c, (long long)hw, total);
+  SR_CHECK_LAUNCH("channel_affine");
+  return SR_OK;
+}
+
+extern "C" int sr_lrelu_fwd_f32(const float* x, float* y, float slope, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && n > 0, "sr_lrelu_fwd_f32: bad argument");
+  hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, slope, (long long)n);
+  SR_CHECK_LAUNCH("lrelu_fwd");
   return SR_OK;
 }

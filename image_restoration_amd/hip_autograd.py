@@ -367,3 +367,84 @@ class SpectralNormFn(torch.autograd.Function):
                                                     rows, cols, gw.data_ptr(), ws.data_ptr(), wsb, _stream(dev)),
                        'sr_spectral_norm_bwd_f32')
         return gw, None, None, None, None
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=2, stride=2) on CB8 (sr_maxpool2x2_fwd_f32 / sr_maxpool2x2_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, cb, h, w, _ = x.shape
+        y = torch.empty((n, cb, h // 2, w // 2, 8), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_maxpool2x2_fwd_f32(x.data_ptr(), y.data_ptr(), n, cb, h, w, _stream(x.device)), 'sr_maxpool2x2_fwd_f32')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, = ctx.saved_tensors
+        n, cb, h, w, _ = x.shape
+        dx = torch.empty_like(x)
+        gy = gy.contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_maxpool2x2_bwd_f32(x.data_ptr(), gy.data_ptr(), dx.data_ptr(), n, cb, h, w, _stream(x.device)),
+                       'sr_maxpool2x2_bwd_f32')
+        return dx
+
+
+class ChannelAffineFn(torch.autograd.Function):
+    """y[n][c] = x[n][c] * a[c] + b[c] on NCHW fp32 (constants a, b: the VGG input normalisation) — sr_channel_affine_f32."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_channel_affine_f32(x.data_ptr(), y.data_ptr(), a.data_ptr(), b.data_ptr(), n, c, h * w, _stream(x.device)),
+                       'sr_channel_affine_f32')
+        ctx.save_for_backward(a)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        a, = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, c, h, w = gy.shape
+        dx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            _lib.check(lib.sr_channel_affine_f32(gy.data_ptr(), dx.data_ptr(), a.data_ptr(), None, n, c, h * w, _stream(gy.device)),
+                       'sr_channel_affine_f32')
+        return dx, None, None
+
+
+class LReLUFn(torch.autograd.Function):
+    """Stand-alone LeakyReLU(slope) / ReLU (slope 0) on any contiguous fp32 tensor (sr_lrelu_fwd_f32 / sr_lrelu_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_lrelu_fwd_f32(x.data_ptr(), y.data_ptr(), slope, x.numel(), _stream(x.device)), 'sr_lrelu_fwd_f32')
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        y, = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            _lib.check(lib.sr_lrelu_bwd_f32(gy.data_ptr(), y.data_ptr(), dx.data_ptr(), ctx.slope, gy.numel(), _stream(gy.device)),
+                       'sr_lrelu_bwd_f32')
+        return dx, None

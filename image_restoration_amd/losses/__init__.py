@@ -4,8 +4,9 @@ from copy import deepcopy
 
 from ..utils.registry import LOSS_REGISTRY
 from .losses import GANLoss, L1Loss  # noqa: F401
+from .perceptual_loss import PerceptualLoss  # noqa: F401
 
-__all__ = ['build_loss', 'L1Loss', 'GANLoss']
+__all__ = ['build_loss', 'L1Loss', 'GANLoss', 'PerceptualLoss']
 
 
 def build_loss(opt):

@@ -29,6 +29,14 @@ class ESRGANModel(SRGANModel):
                 l_g_pix = self.cri_pix(self.output, self.gt)
                 l_g_total = l_g_total + l_g_pix
                 loss_dict['l_g_pix'] = l_g_pix
+            if self.cri_perceptual:  # sr(gan)_model.py: perceptual (and style) terms of the generator loss
+                l_g_percep, l_g_style = self.cri_perceptual(self.output, self.gt)
+                if l_g_percep is not None:
+                    l_g_total = l_g_total + l_g_percep
+                    loss_dict['l_g_percep'] = l_g_percep
+                if l_g_style is not None:
+                    l_g_total = l_g_total + l_g_style
+                    loss_dict['l_g_style'] = l_g_style
             # relativistic gan: real logits are detached (:38), fake logits carry the graph into G (:39)
             with torch.no_grad():
                 real_d_pred = self.net_d(self.gt)

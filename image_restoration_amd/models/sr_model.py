@@ -51,9 +51,9 @@ class SRModel(BaseModel):
         train_opt = self.opt['train']
         self._init_ema(train_opt)
         self.cri_pix = build_loss(train_opt['pixel_opt']).to(self.device) if train_opt.get('pixel_opt') else None
-        if train_opt.get('perceptual_opt'):
-            raise NotImplementedError('PerceptualLoss (VGG19 features) is not on the HIP path yet (SURVEY.md §8 f2)')
-        self.cri_perceptual = None
+        # perceptual loss (losses.py:249-356 on HIP VGG features; the frozen VGG is not optimised)
+        self.cri_perceptual = (build_loss(train_opt['perceptual_opt']).to(self.device)
+                               if train_opt.get('perceptual_opt') else None)
         if self.cri_pix is None and self.cri_perceptual is None:
             raise ValueError('Both pixel and perceptual losses are None.')
         self.setup_optimizers()
@@ -86,9 +86,20 @@ class SRModel(BaseModel):
         self.optimizer_g.zero_grad()
         self.output = self.net_g(self.lq)
         loss_dict = OrderedDict()
-        l_pix = self.cri_pix(self.output, self.gt)
-        loss_dict['l_pix'] = l_pix
-        l_pix.backward()
+        l_total = 0
+        if self.cri_pix:  # sr_model.py:97-108
+            l_pix = self.cri_pix(self.output, self.gt)
+            l_total = l_total + l_pix
+            loss_dict['l_pix'] = l_pix
+        if self.cri_perceptual:
+            l_percep, l_style = self.cri_perceptual(self.output, self.gt)
+            if l_percep is not None:
+                l_total = l_total + l_percep
+                loss_dict['l_percep'] = l_percep
+            if l_style is not None:
+                l_total = l_total + l_style
+                loss_dict['l_style'] = l_style
+        l_total.backward()
         self._step(self.optimizer_g)
         self.log_dict = self.reduce_loss_dict(loss_dict)
         if self.ema_decay > 0:

@@ -27,9 +27,9 @@ class SRGANModel(SRModel):
         self.net_g.train()
         self.net_d.train()
         self.cri_pix = build_loss(train_opt['pixel_opt']).to(self.device) if train_opt.get('pixel_opt') else None
-        if train_opt.get('perceptual_opt'):
-            raise NotImplementedError('PerceptualLoss (VGG19 features) is not on the HIP path yet (SURVEY.md §8 f2)')
-        self.cri_perceptual = None
+        # perceptual loss (losses.py:249-356 on HIP VGG features; the frozen VGG is not optimised)
+        self.cri_perceptual = (build_loss(train_opt['perceptual_opt']).to(self.device)
+                               if train_opt.get('perceptual_opt') else None)
         if train_opt.get('gan_opt'):
             self.cri_gan = build_loss(train_opt['gan_opt']).to(self.device)
         self.net_d_iters = train_opt.get('net_d_iters', 1)
@@ -64,6 +64,14 @@ class SRGANModel(SRModel):
                 l_g_pix = self.cri_pix(self.output, self.gt)
                 l_g_total = l_g_total + l_g_pix
                 loss_dict['l_g_pix'] = l_g_pix
+            if self.cri_perceptual:  # sr(gan)_model.py: perceptual (and style) terms of the generator loss
+                l_g_percep, l_g_style = self.cri_perceptual(self.output, self.gt)
+                if l_g_percep is not None:
+                    l_g_total = l_g_total + l_g_percep
+                    loss_dict['l_g_percep'] = l_g_percep
+                if l_g_style is not None:
+                    l_g_total = l_g_total + l_g_style
+                    loss_dict['l_g_style'] = l_g_style
             fake_g_pred = self.net_d(self.output)
             l_g_gan = self.cri_gan(fake_g_pred, True, is_disc=False)
             l_g_total = l_g_total + l_g_gan

@@ -226,6 +226,15 @@ int sr_psnr_sse_f32(const float* a, const float* b, int n, int c, int h, int w, 
 int sr_ssim_sum_f32(const float* a, const float* b, int n, int c, int h, int w, int crop_border, float* sum, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* VGG feature extractor of PerceptualLoss (vgg_arch.py:55-162, losses.py:249-356): nn.MaxPool2d(2, 2) on CB8 (floor
+ * mode; backward routes a window's gradient to its first maximum in scan order, like torch), the input normalisation
+ * y[n][c] = x[n][c] * a[c] + b[c] on NCHW (b NULL = its backward), and a stand-alone LeakyReLU / ReLU (slope 0) for
+ * feature layers requested before their activation. */
+int sr_maxpool2x2_fwd_f32(const float* x, float* y, int n, int cblocks, int h, int w, void* stream);
+int sr_maxpool2x2_bwd_f32(const float* x, const float* dy, float* dx, int n, int cblocks, int h, int w, void* stream);
+int sr_channel_affine_f32(const float* x, float* y, const float* a, const float* b, int n, int c, int64_t hw, void* stream);
+int sr_lrelu_fwd_f32(const float* x, float* y, float slope, int64_t n, void* stream);
+
 /* out[0] = mean(x) */
 int sr_mean_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 /* L1Loss(loss_weight, reduction='mean') (losses.py:80-106): loss[0] = weight*mean|pred-target|;

@@ -70,7 +70,8 @@ def test_train_entry_point_runs_saves_and_resumes(cuda, tmp_path):
     assert (exp / 'models' / 'net_g_4.pth').exists() and (exp / 'models' / 'net_d_4.pth').exists()
     assert (exp / 'training_states' / '4.state').exists() and (exp / 'models' / 'net_g_latest.pth').exists()
     log = model.get_current_log()
-    assert set(log) == {'l_g_pix', 'l_g_gan', 'l_d_real', 'l_d_fake', 'out_d_real', 'out_d_fake'}
+    # the option file carries the reference's full generator loss: pixel + perceptual (VGG19 conv5_4) + relativistic GAN
+    assert set(log) == {'l_g_pix', 'l_g_percep', 'l_g_gan', 'l_d_real', 'l_d_fake', 'out_d_real', 'out_d_fake'}
     assert all(np.isfinite(v) for v in log.values())
     assert abs(model.get_current_learning_rate()[0] - 5e-5) < 1e-12  # milestone 4 halved 1e-4
     assert np.isfinite(model.metric_results['psnr']) and 0 < model.metric_results['ssim'] <= 1  # validation ran (val_freq, end)
