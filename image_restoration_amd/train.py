@@ -13,7 +13,7 @@ import time
 import torch
 from torch.utils.data import DataLoader
 
-from .data import EnlargedSampler
+from .data import CPUPrefetcher, CUDAPrefetcher, EnlargedSampler
 from .models import build_model
 from .utils.options import dict2str, parse_options
 from .utils.registry import DATASET_REGISTRY
@@ -92,9 +92,18 @@ def train_pipeline(root_path, argv=None):
     save_freq = opt['logger']['save_checkpoint_freq']
     warmup = opt['train'].get('warmup_iter', -1)
     t_iter = time.time()
+    # datasets.train.prefetch_mode: None / 'cpu' iterate the loader, 'cuda' stages the next batch on a copy stream
+    prefetch_mode = next(v for v in opt['datasets'].values() if v['phase'] == 'train').get('prefetch_mode')
+    if prefetch_mode is None or prefetch_mode == 'cpu':
+        prefetcher = CPUPrefetcher(loader)
+    elif prefetch_mode == 'cuda':
+        prefetcher = CUDAPrefetcher(loader, opt)
+    else:
+        raise ValueError(f"Wrong prefetch_mode {prefetch_mode}. Supported ones are: None, 'cuda', 'cpu'.")
     for epoch in range(start_epoch, total_epochs + 1):
         sampler.set_epoch(epoch)
-        for data in loader:
+        prefetcher.reset()
+        while (data := prefetcher.next()) is not None:
             current_iter += 1
             if current_iter > total_iters:
                 break

@@ -45,3 +45,23 @@ def tensor2img(tensor, rgb2bgr=True, out_type=np.uint8, min_max=(0, 1)):
             img = (img * 255.0).round()
         result.append(np.ascontiguousarray(img).astype(out_type))
     return result[0] if len(result) == 1 else result  # a one-element list unwraps, like the reference (:92-94)
+
+
+def imfrombytes(content, flag='color', float32=False):
+    """Decode image bytes to an HWC **BGR** ndarray like cv2.imdecode (img_util.py:114-135): 'color' -> 3 channels,
+    'grayscale' -> 2-D, 'unchanged' -> as stored (alpha kept, channel order BGR[A]).  Decoded with PIL (cv2 is absent)."""
+    import io
+    from PIL import Image
+    img = Image.open(io.BytesIO(content))
+    if flag == 'color':
+        arr = np.asarray(img.convert('RGB'))[:, :, ::-1]
+    elif flag == 'grayscale':
+        arr = np.asarray(img.convert('L'))
+    elif flag == 'unchanged':
+        arr = np.asarray(img)
+        if arr.ndim == 3 and arr.shape[2] >= 3:
+            arr = np.concatenate([arr[:, :, 2::-1], arr[:, :, 3:]], axis=2)
+    else:
+        raise KeyError(flag)
+    arr = np.ascontiguousarray(arr)
+    return arr.astype(np.float32) / 255. if float32 else arr

@@ -1,0 +1,144 @@
+"""Host input pipeline: path pairing, paired crop / augmentation geometry, PairedImageDataset and the
+prefetchers, on temporary PNG folders.  cv2 / lmdb are not in the image, so this is pinned to the published behaviour of
+basicsr/data/{paired_image_dataset,transforms,data_util}.py only (geometry and value-range properties, seeded draws)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from image_restoration_amd.data import CPUPrefetcher, CUDAPrefetcher, PairedImageDataset
+from image_restoration_amd.data.data_util import paired_paths_from_folder, paired_paths_from_meta_info_file
+from image_restoration_amd.data.transforms import augment, mod_crop, paired_random_crop
+from image_restoration_amd.utils.img_util import imfrombytes
+from image_restoration_amd.utils.registry import DATASET_REGISTRY
+
+
+def _coord_pair(h, w, scale):
+    """LQ image whose pixel encodes (y, x); GT = its nearest x scale upsampling, so crops / flips stay checkable."""
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    lq = np.stack([yy, xx, (yy + xx) % 7], axis=2).astype(np.uint8)
+    return lq, lq.repeat(scale, 0).repeat(scale, 1)
+
+
+@pytest.fixture()
+def folders(tmp_path):
+    gt_dir, lq_dir = tmp_path / 'gt', tmp_path / 'lq'
+    gt_dir.mkdir(), lq_dir.mkdir()
+    for i, (h, w) in enumerate([(20, 24), (16, 16), (18, 30)]):
+        lq, gt = _coord_pair(h, w, 4)
+        Image.fromarray(gt).save(gt_dir / f'im{i}.png')  # stored RGB
+        Image.fromarray(lq).save(lq_dir / f'im{i}x4.png')
+    return str(gt_dir), str(lq_dir)
+
+
+def test_path_pairing(folders, tmp_path):
+    gt_dir, lq_dir = folders
+    paths = paired_paths_from_folder([lq_dir, gt_dir], ['lq', 'gt'], '{}x4')
+    assert [os.path.basename(p['gt_path']) for p in paths] == ['im0.png', 'im1.png', 'im2.png']
+    assert [os.path.basename(p['lq_path']) for p in paths] == ['im0x4.png', 'im1x4.png', 'im2x4.png']
+    with pytest.raises(AssertionError):
+        paired_paths_from_folder([lq_dir, gt_dir], ['lq', 'gt'], '{}')  # template does not match the LQ names
+    meta = tmp_path / 'meta.txt'
+    meta.write_text('im2.png (72,120,3)\nim0.png (80,96,3)\n')
+    paths = paired_paths_from_meta_info_file([lq_dir, gt_dir], ['lq', 'gt'], str(meta), '{}x4')
+    assert [os.path.basename(p['lq_path']) for p in paths] == ['im2x4.png', 'im0x4.png']
+
+
+def test_imfrombytes_is_bgr(folders):
+    gt_dir, _ = folders
+    raw = open(os.path.join(gt_dir, 'im0.png'), 'rb').read()
+    rgb = np.asarray(Image.open(os.path.join(gt_dir, 'im0.png')))
+    img = imfrombytes(raw)
+    assert img.dtype == np.uint8 and np.array_equal(img, rgb[:, :, ::-1])
+    f = imfrombytes(raw, float32=True)
+    assert f.dtype == np.float32 and np.array_equal(f, img.astype(np.float32) / 255.)
+    assert imfrombytes(raw, flag='grayscale').shape == rgb.shape[:2]
+
+
+def test_paired_random_crop_and_augment_geometry():
+    lq, gt = _coord_pair(20, 24, 4)
+    random.seed(3)
+    st = random.getstate()
+    g, l = paired_random_crop(gt, lq, 32, 4)
+    random.setstate(st)
+    top, left = random.randint(0, 20 - 8), random.randint(0, 24 - 8)  # the documented draw order: top then left
+    assert l.shape == (8, 8, 3) and g.shape == (32, 32, 3)
+    assert np.array_equal(l, lq[top:top + 8, left:left + 8]) and np.array_equal(g, gt[4 * top:4 * top + 32, 4 * left:4 * left + 32])
+    with pytest.raises(ValueError):
+        paired_random_crop(gt[:-1], lq, 32, 4)
+    with pytest.raises(ValueError):
+        paired_random_crop(gt, lq, 128, 4)
+    seen = set()
+    for seed in range(40):
+        random.seed(seed)
+        (ga, la), status = augment([g, l], True, True, return_status=True)
+        seen.add(status)
+        assert np.array_equal(ga, la.repeat(4, 0).repeat(4, 1))  # same symmetry on both images
+        ref = l
+        if status[0]:
+            ref = ref[:, ::-1]
+        if status[1]:
+            ref = ref[::-1]
+        if status[2]:
+            ref = ref.transpose(1, 0, 2)
+        assert np.array_equal(la, ref) and la.flags['C_CONTIGUOUS']
+    assert len(seen) == 8  # all elements of the dihedral group show up
+    random.seed(0)
+    assert np.array_equal(augment(l, False, False), l)
+    assert mod_crop(gt[:79, :93], 4).shape == (76, 92, 3)
+
+
+def test_paired_image_dataset_train_and_val(folders):
+    gt_dir, lq_dir = folders
+    base = dict(name='t', type='PairedImageDataset', dataroot_gt=gt_dir, dataroot_lq=lq_dir, filename_tmpl='{}x4',
+                io_backend=dict(type='disk'), scale=4)
+    assert DATASET_REGISTRY.get('PairedImageDataset') is PairedImageDataset
+    val = PairedImageDataset(dict(base, phase='val'))
+    assert len(val) == 3
+    item = val[0]
+    assert item['lq'].shape == (3, 20, 24) and item['gt'].shape == (3, 80, 96) and item['lq'].dtype == torch.float32
+    lq, _ = _coord_pair(20, 24, 4)
+    assert torch.equal(item['lq'], torch.from_numpy(lq.transpose(2, 0, 1).astype(np.float32) / 255.))  # RGB, CHW, [0, 1]
+    assert item['gt_path'].endswith('im0.png') and item['lq_path'].endswith('im0x4.png')
+    train = PairedImageDataset(dict(base, phase='train', gt_size=32, use_flip=True, use_rot=True))
+    random.seed(5)
+    for i in range(3):
+        item = train[i]
+        assert item['lq'].shape == (3, 8, 8) and item['gt'].shape == (3, 32, 32)
+        assert torch.equal(item['gt'], item['lq'].repeat_interleave(4, 1).repeat_interleave(4, 2))
+    norm = PairedImageDataset(dict(base, phase='val', mean=[0.5, 0.5, 0.5], std=[0.25, 0.5, 1.0]))[1]
+    ref = val[1]
+    std = torch.tensor([0.25, 0.5, 1.0]).view(3, 1, 1)
+    assert torch.allclose(norm['lq'], (ref['lq'] - 0.5) / std) and torch.allclose(norm['gt'], (ref['gt'] - 0.5) / std)
+
+
+def test_file_client_backends(folders):
+    from image_restoration_amd.data.file_client import FileClient
+    gt_dir, _ = folders
+    p = os.path.join(gt_dir, 'im1.png')
+    assert FileClient('disk').get(p) == open(p, 'rb').read()
+    with pytest.raises(ValueError):
+        FileClient('memcached')
+    try:
+        import lmdb  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):  # loud, not a silent switch to another backend
+            FileClient('lmdb', db_paths=['a.lmdb'], client_keys=['gt'])
+
+
+def test_prefetchers_iterate_a_loader(folders):
+    gt_dir, lq_dir = folders
+    ds = PairedImageDataset(dict(name='t', type='PairedImageDataset', dataroot_gt=gt_dir, dataroot_lq=lq_dir, filename_tmpl='{}x4',
+                                 io_backend=dict(type='disk'), scale=4, phase='train', gt_size=32, use_flip=False, use_rot=False))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, drop_last=False)
+    for pf in (CPUPrefetcher(loader), CUDAPrefetcher(loader, dict(num_gpu=0))):
+        for _ in range(2):  # two epochs through reset()
+            pf.reset()
+            sizes = []
+            while (b := pf.next()) is not None:
+                sizes.append(b['lq'].shape[0])
+                assert b['gt'].shape[1:] == (3, 32, 32) and len(b['gt_path']) == b['lq'].shape[0]
+            assert sizes == [2, 1]

@@ -33,6 +33,7 @@ def test_sampler_matches_reference_streams(golden):
 @pytest.mark.parametrize('path,is_train', [
     ('options/train/ESRGAN/train_ESRGAN_x4_synthetic.yml', True),
     ('options/train/ESRGAN/train_RRDBNet_PSNR_x4_synthetic.yml', True),
+    ('options/train/ESRGAN/train_RRDBNet_PSNR_x4_folders.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml', True),
