@@ -3,9 +3,11 @@
 Counterpart of basicsr/losses/losses.py:249-356 with the reference's constructor: ``PerceptualLoss(layer_weights,
 vgg_type='vgg19', use_input_norm=True, range_norm=False, perceptual_weight=1.0, style_weight=0., criterion='l1')``;
 ``forward(x, gt) -> (percep_loss | None, style_loss | None)``.  Features come from archs/vgg_arch.py (HIP convolutions and
-pooling), the criterion is the HIP L1 reduction.  The Gram-matrix style term and the 'fro' criterion are not on the path
-(style_weight is 0 in the reference's ESRGAN recipe, train_ESRGAN_x4.yml:88-97); 'l2' raises AttributeError in the reference
-itself (torch.nn.L2loss does not exist, losses.py:290)."""
+pooling), the 'l1' criterion is the HIP L1 reduction.  The Gram matrices of the style term are a plain batched GEMM
+(``torch.bmm`` = rocBLAS) over the NCHW features and the 'fro' criterion is ``torch.linalg.norm`` of the difference, both
+under torch autograd on top of the HIP feature extractor.  'l2' raises AttributeError in the reference itself
+(torch.nn.L2loss does not exist, losses.py:290) and NotImplementedError here."""
+import torch
 from torch import nn
 
 from ..archs.vgg_arch import VGGFeatureExtractor
@@ -25,12 +27,22 @@ class PerceptualLoss(nn.Module):
         self.criterion_type = criterion
         if criterion == 'l1':
             self.criterion = L1Loss()
-        elif criterion in ('l2', 'fro'):
-            raise NotImplementedError(f"criterion '{criterion}' is not on the HIP path (the reference's 'l2' does not run either)")
-        else:
+        elif criterion == 'fro':
+            self.criterion = None
+        else:  # 'l2' included: the reference's branch for it cannot run
             raise NotImplementedError(f'{criterion} criterion has not been supported.')
-        if style_weight > 0:
-            raise NotImplementedError('the Gram-matrix style loss is not on the HIP path')
+
+    def _distance(self, a, b):
+        if self.criterion_type == 'fro':
+            return torch.linalg.norm((a - b).flatten())
+        return self.criterion(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def _gram_mat(x):
+        """[n, c, h, w] -> [n, c, c] = F F^T / (c h w) (losses.py:342-356)."""
+        n, c, h, w = x.size()
+        features = x.reshape(n, c, h * w)
+        return features.bmm(features.transpose(1, 2)) / (c * h * w)
 
     def forward(self, x, gt):
         x_features = self.vgg(x)
@@ -38,8 +50,16 @@ class PerceptualLoss(nn.Module):
         if self.perceptual_weight > 0:
             percep_loss = 0
             for k in x_features.keys():
-                percep_loss = percep_loss + self.criterion(x_features[k], gt_features[k].detach()) * self.layer_weights[k]
+                percep_loss = percep_loss + self._distance(x_features[k], gt_features[k].detach()) * self.layer_weights[k]
             percep_loss = percep_loss * self.perceptual_weight
         else:
             percep_loss = None
-        return percep_loss, None
+        if self.style_weight > 0:
+            style_loss = 0
+            for k in x_features.keys():
+                style_loss = style_loss + self._distance(self._gram_mat(x_features[k]),
+                                                         self._gram_mat(gt_features[k].detach())) * self.layer_weights[k]
+            style_loss = style_loss * self.style_weight
+        else:
+            style_loss = None
+        return percep_loss, style_loss

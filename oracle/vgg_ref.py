@@ -37,8 +37,21 @@ def vgg_features(x, sd, layer_name_list, vgg_type='vgg19', use_input_norm=True, 
     return out
 
 
-def perceptual_loss(x, gt, sd, layer_weights, perceptual_weight=1.0, **kw):
-    """PerceptualLoss.forward with criterion 'l1', style_weight 0 (losses.py:301-338)."""
+def _gram(x):
+    n, c, h, w = x.shape
+    f = x.reshape(n, c, h * w)
+    return f.bmm(f.transpose(1, 2)) / (c * h * w)
+
+
+def perceptual_loss(x, gt, sd, layer_weights, perceptual_weight=1.0, style_weight=0.0, criterion='l1', **kw):
+    """PerceptualLoss.forward (losses.py:301-356): returns the perceptual term, or (perceptual, style) when
+    style_weight > 0; criterion 'l1' or 'fro'."""
     fx = vgg_features(x, sd, list(layer_weights), **kw)
     fg = vgg_features(gt.detach(), sd, list(layer_weights), **kw)
-    return sum(F.l1_loss(fx[k], fg[k]) * w for k, w in layer_weights.items()) * perceptual_weight
+
+    def dist(a, b):
+        return F.l1_loss(a, b) if criterion == 'l1' else torch.norm(a - b, p='fro')
+    percep = sum(dist(fx[k], fg[k]) * w for k, w in layer_weights.items()) * perceptual_weight
+    if style_weight > 0:
+        return percep, sum(dist(_gram(fx[k]), _gram(fg[k])) * w for k, w in layer_weights.items()) * style_weight
+    return percep
