@@ -177,6 +177,56 @@ def train_mode(args, world, rank, dev, dist, backend):
         dist.destroy_process_group()
 
 
+def tiled_mode(args, world, rank, dev, dist, backend):
+    """Secondary line (BASELINE configs[4], the fifth): one 4K frame (3840x2160 LR) through the tiler — 512x512 cells + 16 px pad, the
+    cells sharded over the ranks, HR crops gathered onto rank 0 by one RCCL gather (uint8 output convention).  One frame is
+    split over all ranks, so this is strong scaling; a step = one whole frame assembled on rank 0."""
+    import image_restoration_amd as ira
+    from image_restoration_amd.tiling import plan_tiles, tiled_forward
+    from image_restoration_amd.utils import synth
+    net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
+    net.set_compute_dtype(args.dtype)
+    H, W = 2160, 3840
+    img = torch.from_numpy(synth.uniform_input(77, (1, 3, H, W))).to(dev)  # the same frame on every rank
+
+    def step():
+        return tiled_forward(net, img, tile=512, pad=16, scale=4, max_batch=args.tile_batch, rank=rank, world_size=world,
+                             out_dtype=torch.uint8)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        assert out.shape == (1, 3, 4 * H, 4 * W) and out.dtype == torch.uint8
+        print(json.dumps({
+            'metric': '4K frames/sec (3840x2160 -> 15360x8640 x4 SR, 23-block RRDBNet, 512x512 tiles + 16 px pad)',
+            'value': round(args.steps / dt, 4), 'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[4]: tiled 4K frame, %d cells sharded over the ranks, uint8 crops gathered '
+                                   'on rank 0' % len(plan_tiles(H, W, 512, 16)), 'tile': 512, 'tile_pad': 16,
+                       'parallelism': f'tile-sharded x{world}, one gather per frame'},
+            'lr_megapixels_per_sec': round(args.steps * H * W / dt / 1e6, 3)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,9 +236,11 @@ def main():
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help="fp32 = the BASELINE metric (default, the judged line); bf16 = secondary reduced-precision run")
     ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning)')
-    ap.add_argument('--mode', choices=('infer', 'train'), default='infer',
+    ap.add_argument('--tile-batch', type=int, default=4, help='--mode tiled: cells per forward')
+    ap.add_argument('--mode', choices=('infer', 'train', 'tiled'), default='infer',
                     help='infer = the BASELINE metric (default, the judged line); train = secondary line: full ESRGAN '
-                         'optimize_parameters steps (BASELINE configs 3-4), data-parallel over the ranks')
+                         'optimize_parameters steps (BASELINE configs 3-4), data-parallel over the ranks; tiled = secondary line: '
+                         'one 4K frame through the tile-sharded path (BASELINE configs 5)')
     ap.add_argument('--batch', type=int, default=32, help='--mode train: batch per GPU')
     ap.add_argument('--lq', type=int, default=32, help='--mode train: LR patch size (gt = 4x)')
     ap.add_argument('--disc', choices=('vgg', 'unet'), default='vgg', help='--mode train: discriminator')
@@ -214,6 +266,8 @@ def main():
 
     if args.mode == 'train':
         return train_mode(args, world, rank, dev, dist, backend)
+    if args.mode == 'tiled':
+        return tiled_mode(args, world, rank, dev, dist, backend)
 
     import image_restoration_amd as ira
     from image_restoration_amd.utils import synth

@@ -7,7 +7,7 @@ on each side (clipped at the frame border), super-resolve the padded cell, and p
 
 Cells are independent, so they shard across data-parallel ranks with no data-path collective: rank r takes cells
 r, r+world, ...; cells of equal padded shape are batched into one forward; the HR crops meet on the assembling
-rank by one gather (or stay sharded if the caller wants them in place).
+rank by one device-side gather (the path's only exchange step).
 """
 import torch
 
@@ -42,25 +42,63 @@ def _run_cells(net, img, cells, scale, max_batch):
     return out
 
 
-def tiled_forward(net, img, tile=512, pad=16, scale=4, max_batch=8, rank=0, world_size=1, group=None, dst=0):
+def quantise_u8(t):
+    """tensor2img's output convention (img_util.py:98-147 of the reference): clamp to [0, 1], x255, round, uint8."""
+    return (t.clamp(0, 1) * 255.0).round().to(torch.uint8)
+
+
+def _gather_crops(crops, cells, world_size, rank, dst, group, n_out, scale, dtype, device):
+    """The exchange step of the sharded tiler: every rank flattens its HR crops (cell-index order) into one device buffer
+    and rank `dst` receives them with ONE `gather` (RCCL over xGMI on GPUs; CPU tensors under gloo).  Sizes follow from the
+    tile plan, which every rank knows, so no size exchange is needed; buffers are padded to the largest share."""
+    import torch.distributed as dist
+
+    def numel(i):
+        y0, y1, x0, x1 = cells[i][1][0]
+        return n_out * (y1 - y0) * scale * (x1 - x0) * scale
+    owned = [[i for i, _ in cells if i % world_size == r] for r in range(world_size)]
+    cap = max(sum(numel(i) for i in o) for o in owned)
+    on_host = dist.get_backend(group) == 'gloo'
+    buf_dev = torch.device('cpu') if on_host else device
+    send = torch.zeros(cap, dtype=dtype, device=device)
+    off = 0
+    for i in owned[rank]:
+        send[off:off + numel(i)] = crops[i].reshape(-1)
+        off += numel(i)
+    send = send.to(buf_dev)
+    recv = [torch.empty(cap, dtype=dtype, device=buf_dev) for _ in range(world_size)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = {}
+    for r in range(world_size):
+        off = 0
+        part = recv[r].to(device)
+        for i in owned[r]:
+            y0, y1, x0, x1 = cells[i][1][0]
+            out[i] = part[off:off + numel(i)].view(1, n_out, (y1 - y0) * scale, (x1 - x0) * scale)
+            off += numel(i)
+    return out
+
+
+def tiled_forward(net, img, tile=512, pad=16, scale=4, max_batch=8, rank=0, world_size=1, group=None, dst=0,
+                  out_dtype=torch.float32):
     """img [1, C, H, W] on the HIP device -> [1, C_out, scale*H, scale*W] on rank `dst` (None elsewhere when
-    world_size > 1).  With world_size > 1 every rank must call this with the same image."""
-    assert img.dim() == 4 and img.size(0) == 1
+    world_size > 1).  With world_size > 1 every rank must call this with the same image.  out_dtype torch.uint8 applies the
+    output convention (clamp, x255, round) on the producing rank, which also cuts the exchange to a quarter."""
+    assert img.dim() == 4 and img.size(0) == 1 and out_dtype in (torch.float32, torch.uint8)
     h, w = img.shape[2:]
     cells = list(enumerate(plan_tiles(h, w, tile, pad)))
     mine = [c for c in cells if c[0] % world_size == rank]
     crops = _run_cells(net, img, mine, scale, max_batch)
+    if out_dtype == torch.uint8:
+        crops = {i: quantise_u8(c) for i, c in crops.items()}
+    n_out = next(iter(crops.values())).size(1) if crops else getattr(net, 'num_out_ch', img.size(1))
     if world_size > 1:
-        import torch.distributed as dist
-        gathered = [None] * world_size if rank == dst else None
-        dist.gather_object({i: c.cpu() for i, c in crops.items()}, gathered, dst=dst, group=group)
-        if rank != dst:
+        crops = _gather_crops(crops, cells, world_size, rank, dst, group, n_out, scale, out_dtype, img.device)
+        if crops is None:
             return None
-        crops = {}
-        for part in gathered:
-            crops.update({i: c.to(img.device) for i, c in part.items()})
-    n_out = next(iter(crops.values())).size(1)
-    out = torch.empty((1, n_out, h * scale, w * scale), dtype=torch.float32, device=img.device)
+    out = torch.empty((1, n_out, h * scale, w * scale), dtype=out_dtype, device=img.device)
     for i, ((y0, y1, x0, x1), _) in cells:
         out[:, :, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = crops[i]
     return out

@@ -129,3 +129,51 @@ def test_ssim_host_matches_direct_2d_definition():
     assert abs(calculate_ssim(a, b, 4) - np.mean(vals)) < 1e-12
     assert abs(calculate_ssim(a, a, 0) - 1.0) < 1e-12
     assert abs(calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), 4, input_order='CHW') - np.mean(vals)) < 1e-12
+
+
+def _tiler_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from image_restoration_amd.tiling import tiled_forward
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def net(x):  # a stand-in generator with a 3x3 receptive field: x4 nearest upsampling of a box-filtered image
+        y = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode='replicate'), 3, 1)
+        return torch.nn.functional.interpolate(y, scale_factor=4, mode='nearest')
+    img = torch.rand(1, 3, 37, 50, generator=torch.Generator().manual_seed(4))
+    for dt in (torch.float32, torch.uint8):
+        out = tiled_forward(net, img, tile=16, pad=2, scale=4, max_batch=2, rank=rank, world_size=world, dst=1, out_dtype=dt)
+        q.put((rank, str(dt), None if out is None else out.numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_tiler_gathers_the_frame(world):
+    """N>1 tile sharding (SURVEY.md §8 e): cells i % world == rank, one gather to `dst`; the assembled frame equals the
+    single-process result in fp32 and in the uint8 output convention; other ranks get None."""
+    import torch.multiprocessing as mp
+    from image_restoration_amd.tiling import quantise_u8, tiled_forward
+
+    def net(x):
+        y = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode='replicate'), 3, 1)
+        return torch.nn.functional.interpolate(y, scale_factor=4, mode='nearest')
+    img = torch.rand(1, 3, 37, 50, generator=torch.Generator().manual_seed(4))
+    ref = tiled_forward(net, img, tile=16, pad=2, scale=4, max_batch=2)
+    assert ref.shape == (1, 3, 148, 200)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_tiler_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, dt, out in res:
+        if rank != 1:
+            assert out is None
+        elif dt == 'torch.float32':
+            assert np.array_equal(out, ref.numpy())
+        else:
+            assert out.dtype == np.uint8 and np.array_equal(out, quantise_u8(ref).numpy())
