@@ -235,7 +235,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help="fp32 = the BASELINE metric (default, the judged line); bf16 = secondary reduced-precision run")
-    ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning)')
+    ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning; 0 = library default)')
     ap.add_argument('--tile-batch', type=int, default=4, help='--mode tiled: cells per forward')
     ap.add_argument('--mode', choices=('infer', 'train', 'tiled'), default='infer',
                     help='infer = the BASELINE metric (default, the judged line); train = secondary line: full ESRGAN '

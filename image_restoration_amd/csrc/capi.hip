@@ -128,13 +128,33 @@ extern "C" int sr_profile_stop(sr_launch_record* out, int capacity, int* count) 
 
 // ---- tuning knob: number of concurrent image groups of the whole-network forward ----
 namespace {
-int g_forward_groups = 1;
+int g_forward_groups = 0;  // 0 = per-path default
 }
 namespace sr {
 int forward_groups() { return g_forward_groups; }
+bool SideStreams::ensure() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (device == dev) return true;
+  for (int i = 0; i < 3; ++i) {
+    if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
+  }
+  if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+  device = dev;
+  return true;
+}
+int& launch_concurrency() {
+  thread_local int c = 1;
+  return c;
+}
+SideStreams& side_streams() {
+  thread_local SideStreams s;
+  return s;
+}
 }  // namespace sr
 extern "C" int sr_set_forward_groups(int groups) {
-  SR_CHECK_ARG(groups >= 1 && groups <= 4, "sr_set_forward_groups: 1..4");
+  SR_CHECK_ARG(groups >= 0 && groups <= 4, "sr_set_forward_groups: 0 (automatic) or 1..4");
   g_forward_groups = groups;
   return SR_OK;
 }

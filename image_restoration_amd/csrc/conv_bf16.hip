@@ -351,7 +351,8 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   // Tile height by launch size: 32-row tiles (8 waves) while they still give every CU a workgroup; smaller inputs
   // (single plate crops, 32x32 training patches) fall to 16-, 8- and 4-row tiles, which cost more halo / weight refill
   // per MFMA but keep CUs from idling while a few workgroups walk K serially.
-  auto wgs = [&](int rows) { return (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, rows) * d->n * groups; };
+  const int conc = sr::launch_concurrency();  // image groups launching side by side (grouped forward)
+  auto wgs = [&](int rows) { return (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, rows) * d->n * groups * conc; };
   int rows;
   if (w8 && wgs(32) >= 256)
     rows = 32;

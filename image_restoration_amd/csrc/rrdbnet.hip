@@ -257,25 +257,6 @@ int forward_body(const sr_rrdbnet_cfg* cfg, const NetPlan& P, const FwdSpace& W,
 
 // Side streams for the image-group split of the inference forward (see forward_impl).  One set per host thread;
 // created on first use, never destroyed (process lifetime), no device memory.
-struct SideStreams {
-  hipStream_t s[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
-  int device = -1;
-  bool ensure() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (device == dev) return true;
-    for (int i = 0; i < 3; ++i) {
-      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
-      if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
-    }
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-    device = dev;
-    return true;
-  }
-};
-thread_local SideStreams g_side;
-
 FwdSpace shift_space(const sr_rrdbnet_cfg* c, const NetPlan& P, const FwdSpace& W, int n0, int h, int w) {
   FwdSpace S = W;
   const size_t hw = (size_t)h * w;
@@ -313,29 +294,16 @@ int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x,
   // covered by the other group's steady state.  Each group keeps >= 512 workgroups per launch (2 per CU).
   const long long wg_per_image = (long long)sr::cdiv(w, 32) * sr::cdiv(h, 8);
   int groups = sr::forward_groups();
+  if (groups == 0) groups = 1;  // fp32 default: no grouping (include/sr_hip.h)
   while (groups > 1 && (n / groups) * wg_per_image < 512) --groups;
   if (groups > n) groups = n;
-  if (groups <= 1 || sr::prof_on() || !g_side.ensure()) return forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train);
+  if (groups <= 1 || sr::prof_on()) return forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train);
   const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
   const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
-  if (hipEventRecord(g_side.fork, stream) != hipSuccess) return SR_ELAUNCH;
-  int rc = SR_OK;
-  int n0 = 0;
-  for (int g = 0; g < groups && rc == SR_OK; ++g) {
-    const int cnt = n / groups + (g < n % groups ? 1 : 0);
-    hipStream_t s = g == 0 ? stream : g_side.s[g - 1];
-    if (g > 0 && hipStreamWaitEvent(s, g_side.fork, 0) != hipSuccess) rc = SR_ELAUNCH;
-    if (rc == SR_OK) {
-      const FwdSpace S = shift_space(cfg, P, W, n0, h, w);
-      rc = forward_body(cfg, P, S, packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train);
-    }
-    if (g > 0) {
-      if (hipEventRecord(g_side.join[g - 1], s) != hipSuccess || hipStreamWaitEvent(stream, g_side.join[g - 1], 0) != hipSuccess)
-        rc = rc ? rc : SR_ELAUNCH;
-    }
-    n0 += cnt;
-  }
-  return rc;
+  return sr::run_image_groups(n, groups, stream, [&](int, int n0, int cnt, hipStream_t s) {
+    const FwdSpace S = shift_space(cfg, P, W, n0, h, w);
+    return forward_body(cfg, P, S, packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train);
+  });
 }
 
 size_t space_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w, int which) {

@@ -129,19 +129,9 @@ BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
   return B;
 }
 
-int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h_in, int w_in,
-              void* workspace, size_t workspace_bytes, hipStream_t stream, bool train, const char* who) {
-  NetPlanH P;
-  SR_CHECK_ARG(make_plan_h(cfg, &P), "%s: bad config", who);
-  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "%s: bad argument", who);
-  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "%s: input not divisible by %d", who, P.unshuffle);
-  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "%s: workspace must be 256-byte aligned", who);
-  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
-  const FwdSpaceH W = carve_fwd_h(cfg, P, n, h, w, (char*)workspace, train);
-  if (W.bytes > workspace_bytes) {
-    sr::set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, W.bytes);
-    return SR_ENOSPACE;
-  }
+// One image range of the forward on one stream; W already points at the range's first image in every buffer.
+int forward_body_h(const sr_rrdbnet_cfg* cfg, const NetPlanH& P, const FwdSpaceH& W, const void* packed, const float* x, float* y,
+                   int n, int h, int w, hipStream_t stream, bool train, const char* who) {
   const long long hw = (long long)h * w;
   const int ctot = P.nfp + 4 * P.gcp;
   const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;  // bf16 elements
@@ -221,6 +211,49 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
   if (rc) return rc;
   return conv(W.hr, feat_ns * 16, 4 * h, 4 * w, 0, y, (long long)cfg->num_out_ch * hw * 16, 1.f, 1.f, nullptr, 0, 0.f, nullptr, 0,
               0.f, 1);
+}
+
+FwdSpaceH shift_space_h(const NetPlanH& P, const FwdSpaceH& W, int n0, int h, int w) {
+  FwdSpaceH S = W;
+  const size_t hw = (size_t)h * w;
+  const int ctot = P.nfp + 4 * P.gcp;
+  S.xin += (size_t)n0 * P.cin0_pad * hw;
+  S.feat0 += (size_t)n0 * P.nfp * hw;
+  for (auto& p : S.cat) p += (size_t)n0 * ctot * hw;
+  S.trunk += (size_t)n0 * P.nfp * hw;
+  S.up1 += (size_t)n0 * P.nfp * hw * 4;
+  S.up2 += (size_t)n0 * P.nfp * hw * 16;
+  S.hr += (size_t)n0 * P.nfp * hw * 16;
+  return S;
+}
+
+int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, float* y, int n, int h_in, int w_in,
+              void* workspace, size_t workspace_bytes, hipStream_t stream, bool train, const char* who) {
+  NetPlanH P;
+  SR_CHECK_ARG(make_plan_h(cfg, &P), "%s: bad config", who);
+  SR_CHECK_ARG(packed && x && y && workspace && n > 0 && h_in > 0 && w_in > 0, "%s: bad argument", who);
+  SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "%s: input not divisible by %d", who, P.unshuffle);
+  SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "%s: workspace must be 256-byte aligned", who);
+  const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  const FwdSpaceH W = carve_fwd_h(cfg, P, n, h, w, (char*)workspace, train);
+  if (W.bytes > workspace_bytes) {
+    sr::set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, W.bytes);
+    return SR_ENOSPACE;
+  }
+  // Image groups on concurrent streams (sr_set_forward_groups): the bf16 layers are 20-80 us launches whose ramp-up, tail
+  // and epilogue drain are a third of their duration; a second group's launches fill those gaps.  Each group keeps at
+  // least 64 workgroups of 32x32 pixels per launch so the tile dispatch of the conv does not fall to the smallest tiles.
+  int groups = sr::forward_groups();
+  if (groups == 0) groups = train ? 1 : 4;  // the training forward (one saved buffer per dense block) measured no gain
+  const long long wg_per_image = (long long)sr::cdiv(w, 32) * sr::cdiv(h, 32);
+  while (groups > 1 && (n / groups) * wg_per_image < 64) --groups;
+  if (groups <= 1 || sr::prof_on()) return forward_body_h(cfg, P, W, packed, x, y, n, h, w, stream, train, who);
+  const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
+  const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
+  return sr::run_image_groups(n, groups, stream, [&](int, int n0, int cnt, hipStream_t s) {
+    return forward_body_h(cfg, P, shift_space_h(P, W, n0, h, w), packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train,
+                          who);
+  });
 }
 }  // namespace
 

@@ -56,7 +56,39 @@ const void* zero_line();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): a per-kernel `static bool` would leave the
 // second device of a process without the attribute.
 int ensure_dynamic_lds(const void* kernel, int bytes);
-int forward_groups();  // image groups of the forward (sr_set_forward_groups; default 1)
+int forward_groups();  // image groups of the forward (sr_set_forward_groups; 0 = the path's own default)
+// Side streams + fork / join events of the calling thread for the grouped forward (created once per device).
+struct SideStreams {
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+  int device = -1;
+  bool ensure();
+};
+SideStreams& side_streams();
+// Number of image groups whose launches run concurrently with the calling thread's (1 outside a grouped forward): the
+// tile dispatch of the convs counts the workgroups of all groups when it decides whether a launch fills the chip.
+int& launch_concurrency();
+// Runs body(g, n0, cnt, stream_g) for `groups` contiguous image ranges of n: group 0 on `stream`, the others on side streams
+// that fork from and join back into `stream` (no host synchronisation; the caller's stream order is preserved).
+template <class Body>
+int run_image_groups(int n, int groups, hipStream_t stream, Body body) {
+  SideStreams& S = side_streams();
+  if (groups <= 1 || !S.ensure()) return body(0, 0, n, stream);
+  if (hipEventRecord(S.fork, stream) != hipSuccess) return SR_ELAUNCH;
+  launch_concurrency() = groups;
+  int rc = SR_OK, n0 = 0;
+  for (int g = 0; g < groups && rc == SR_OK; ++g) {
+    const int cnt = n / groups + (g < n % groups ? 1 : 0);
+    hipStream_t s = g == 0 ? stream : S.s[g - 1];
+    if (g > 0 && hipStreamWaitEvent(s, S.fork, 0) != hipSuccess) rc = SR_ELAUNCH;
+    if (rc == SR_OK) rc = body(g, n0, cnt, s);
+    if (g > 0 && (hipEventRecord(S.join[g - 1], s) != hipSuccess || hipStreamWaitEvent(stream, S.join[g - 1], 0) != hipSuccess))
+      rc = rc ? rc : SR_ELAUNCH;
+    n0 += cnt;
+  }
+  launch_concurrency() = 1;
+  return rc;
+}
 
 #define SR_CHECK_ARG(cond, ...)            \
   do {                                     \

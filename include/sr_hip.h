@@ -283,10 +283,13 @@ int sr_rrdbnet_pack_f32(const sr_rrdbnet_cfg* cfg, const float* const* host_para
 int sr_rrdbnet_forward_f32(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x, float* y, int n, int h,
                            int w, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Tuning knob (process-wide): with groups > 1 the forward cuts the batch into `groups` image groups (1..4) that run
- * the same launch sequence concurrently on internal side streams forked from / joined to `stream` with events
- * (graph-capturable).  Default 1: measured on MI355X the overlap buys < 0.5 % (the per-launch cost is LDS-DMA
- * refill traffic and the output-store drain, not idle CUs), so by default every launch goes to `stream` itself. */
+/* Tuning knob (process-wide): the whole-network forwards can cut the batch into `groups` image groups (1..4) that run
+ * the same launch sequence concurrently on internal side streams forked from / joined to `stream` with events (no host
+ * synchronisation, graph-capturable, results bit-identical).  groups = 0 (default) chooses per path: the fp32 forward uses 1
+ * (measured on MI355X the overlap buys < 0.5 %: its per-launch cost is LDS-DMA refill traffic and the output-store drain,
+ * not idle CUs); the bf16 inference forward uses up to 4 while every group keeps >= 64 workgroups per launch (its 20-80 us launches
+ * spend a third of their time in ramp-up, tail and epilogue drain, which another group's launches fill: +7 % at batch 16,
+ * +13 % at batch 32 of 128x128 tiles; the training forward keeps 1, grouping measured no gain there). */
 int sr_set_forward_groups(int groups);
 
 /* Training: forward that KEEPS every activation the backward needs (one concat buffer per dense block,

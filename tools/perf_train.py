@@ -1,4 +1,4 @@
-"""Times generator forward+backward (argv: batch [fp32|bf16]) and prints per-kernel aggregates from the launch profiler."""
+"""Times generator forward+backward (argv: batch [fp32|bf16] [forward groups, 0 = default]) and prints per-kernel aggregates from the launch profiler."""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +7,8 @@ from image_restoration_amd import _lib
 from image_restoration_amd.utils import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 DT = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+_lib.check(_lib.load().sr_set_forward_groups(G), 'sr_set_forward_groups')
 cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32)
 dev = torch.device('cuda')
 net = ira.build_network(dict(type='RRDBNet', **cfg)).to(dev)
@@ -20,10 +22,10 @@ def step():
     y.backward(gy)
 for _ in range(2): step()
 torch.cuda.synchronize()
-t0 = time.perf_counter(); K = 3
+t0 = time.perf_counter(); K = 6
 for _ in range(K): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(f'{DT} batch {B}: fwd+bwd {dt*1e3:.1f} ms  -> {B/dt:.1f} img/s ; ideal(3x fwd flops @157.3TF) {3*5.8743e11*B/157.3e12*1e3:.1f} ms')
+print(f'{DT} batch {B} groups {G}: fwd+bwd {dt*1e3:.1f} ms  -> {B/dt:.1f} img/s ; ideal(3x fwd flops @157.3TF) {3*5.8743e11*B/157.3e12*1e3:.1f} ms')
 lib = _lib.load(); cap = 8192; recs = (_lib.LaunchRecord * cap)(); n = C.c_int(0)
 lib.sr_profile_start(cap); step(); lib.sr_profile_stop(recs, cap, C.byref(n))
 agg = {}
