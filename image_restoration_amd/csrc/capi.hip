@@ -1,6 +1,7 @@
 // Error reporting and ABI version of libsr_hip.so.
 #include <string.h>
 
+#include <map>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -55,6 +56,7 @@ extern "C" const char* sr_last_error(void) { return g_err; }
 
 // ---- opt-in launch profiler (process-wide, mutex-guarded; off unless sr_profile_start was called).
 // Process-wide because autograd runs the backward launches on its own thread. ----
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -133,9 +135,9 @@ int g_forward_groups = 0;  // 0 = per-path default
 namespace sr {
 int forward_groups() { return g_forward_groups; }
 bool SideStreams::ensure() {
+  if (device >= 0) return true;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
-  if (device == dev) return true;
   for (int i = 0; i < 3; ++i) {
     if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
@@ -148,9 +150,11 @@ int& launch_concurrency() {
   thread_local int c = 1;
   return c;
 }
-SideStreams& side_streams() {
-  thread_local SideStreams s;
-  return s;
+SideStreams& side_streams() {  // one set per (thread, device): streams and events belong to the device they were made on
+  thread_local std::map<int, SideStreams> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return per_device[dev];
 }
 }  // namespace sr
 extern "C" int sr_set_forward_groups(int groups) {
