@@ -340,40 +340,45 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   const int cp = (d->cout + 31) / 32 * 32;
   const int gc = (cp % 64 == 0) ? 64 : 32;
   const int groups = cp / gc;
-  // 8-wave workgroups (32x32-pixel tiles, two waves per SIMD: one wave's LDS latency and barrier wait hide behind the
-  // other's MFMAs, and a chunk of MFMA work is as long as the refill latency) whenever the image has whole 32-row tiles.
-  const bool w8 = p.H % 32 == 0;
+  const bool w8 = p.H % 32 == 0;  // whole 32-row tiles for the 8-wave x 4-row workgroup
   if (d->out_nchw) {
     if (p.out_nb == 0) p.out_nb = (long long)d->cout * p.H * p.W * 4;
     if (gc == 64) return w8 ? launch_h<2, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, true>(p, d->n, groups, stream, d);
     return w8 ? launch_h<1, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, true>(p, d->n, groups, stream, d);
   }
-  // Tile height by launch size: 32-row tiles (8 waves) while they still give every CU a workgroup; smaller inputs
-  // (single plate crops, 32x32 training patches) fall to 16-, 8- and 4-row tiles, which cost more halo / weight refill
-  // per MFMA but keep CUs from idling while a few workgroups walk K serially.
+  // Tile shape by launch size and depth.  Launches of >= 256 tiles with Cin <= 256 (the dense blocks, the head) use 16-row
+  // tiles on 8 waves: 57 KB of LDS, so two workgroups share a CU and one's prologue / epilogue (no loads in flight for the
+  // MFMA loop) overlaps the other's loop — 6-25 % faster than one 32-row workgroup per CU.  Deep layers (Cin > 256: the
+  // discriminator's inner levels) are MFMA-heavier per byte and keep the 32-row tile (less halo and weight refill per
+  // MFMA).  Smaller inputs (single plate crops, 32x32 training patches) fall to 4-wave tiles of 16, 8 and 4 rows, which
+  // cost more halo / weight refill per MFMA but keep CUs from idling while a few workgroups walk K serially.
   const int conc = sr::launch_concurrency();  // image groups launching side by side (grouped forward)
   auto wgs = [&](int rows) { return (long long)sr::cdiv(p.W, 32) * sr::cdiv(p.H, rows) * d->n * groups * conc; };
-  int rows;
-  if (w8 && wgs(32) >= 256)
-    rows = 32;
+  enum Tile { R16_W8, R32_W8, R16_W4, R8_W4, R4_W4 } tile;
+  if (p.H % 16 == 0 && p.cin_blocks <= 16 && wgs(16) >= 256)
+    tile = R16_W8;
+  else if (w8 && wgs(32) >= 256)
+    tile = R32_W8;
   else if (p.H % 16 == 0 && wgs(16) >= 256)
-    rows = 16;
+    tile = R16_W4;
   else if (wgs(8) >= 256 || p.H <= 4)
-    rows = 8;
+    tile = R8_W4;
   else
-    rows = 4;
+    tile = R4_W4;
   if (gc == 64) {
-    switch (rows) {
-      case 32: return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);
-      case 16: return launch_h<2, 4, 4, false>(p, d->n, groups, stream, d);
-      case 8: return launch_h<2, 2, 4, false>(p, d->n, groups, stream, d);
+    switch (tile) {
+      case R16_W8: return launch_h<2, 2, 8, false>(p, d->n, groups, stream, d);
+      case R32_W8: return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);
+      case R16_W4: return launch_h<2, 4, 4, false>(p, d->n, groups, stream, d);
+      case R8_W4: return launch_h<2, 2, 4, false>(p, d->n, groups, stream, d);
       default: return launch_h<2, 1, 4, false>(p, d->n, groups, stream, d);
     }
   }
-  switch (rows) {
-    case 32: return launch_h<1, 4, 8, false>(p, d->n, groups, stream, d);
-    case 16: return launch_h<1, 4, 4, false>(p, d->n, groups, stream, d);
-    case 8: return launch_h<1, 2, 4, false>(p, d->n, groups, stream, d);
+  switch (tile) {
+    case R16_W8: return launch_h<1, 2, 8, false>(p, d->n, groups, stream, d);
+    case R32_W8: return launch_h<1, 4, 8, false>(p, d->n, groups, stream, d);
+    case R16_W4: return launch_h<1, 4, 4, false>(p, d->n, groups, stream, d);
+    case R8_W4: return launch_h<1, 2, 4, false>(p, d->n, groups, stream, d);
     default: return launch_h<1, 1, 4, false>(p, d->n, groups, stream, d);
   }
 }

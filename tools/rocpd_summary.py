@@ -36,9 +36,10 @@ def traffic(out, dbs):
         for k in fetch:
             if k in write and any(t in k for t in ('conv_', 'wgrad')):
                 res[mangled_like(k)] = int((2 * fetch[k] + write[k]) * 1024)
-    for k in list(res):  # bench.py's names omit trailing default template arguments
-        if k.endswith('ELi0ELi4E'):
-            res[k[:-8]] = res[k]
+    for k in list(res):  # bench.py's names omit the trailing default template arguments <.., ABL = 0, NW = 4, WT = 32>
+        for tail in ('ELi0ELi4ELi32E', 'ELi0ELi4E'):
+            if k.startswith('conv_f32_kernel') and k.endswith(tail):
+                res[k[:-len(tail) + 1]] = res[k]
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 
