@@ -36,6 +36,7 @@ struct ConvParamsH {
   int cout_blocks;  // valid 16-channel blocks of the destination (ceil(cout/16))
   int cout;
   int in_h, in_w, H, W, tiles_x, tiles_y;
+  int cogs;         // cout groups (32*COT couts each)
   int src_shift;    // 1: nearest x2 upsample on the fly
   int mask_cbn;
   float slope, alpha, beta1, beta2, mask_slope;
@@ -59,17 +60,22 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous run of the
+  // (tile, cout group) sequence with the cout group fastest: the cout groups of one pixel tile run side by side on one
+  // XCD and share the tile's input through that XCD's L2 (a deep layer with 4-8 cout groups otherwise re-reads its whole
+  // input from HBM once per group), and neighbouring tiles share halo rows and weights.
   int t;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  const int cog = t % p.cogs;
+  t /= p.cogs;
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int n = t / p.tiles_y;
-  const int cog = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * TH;
   const long long plane_b = (long long)p.in_h * p.in_w * 32;  // bytes of one 16-channel block plane
   const char* in_n = p.in + (long long)n * p.in_nb;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
   }
   if (p.dbg && lane == 0) {
     tk[5] = __builtin_readcyclecounter();
-    long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+    long long* o = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
     o[0] = tk[0]; o[1] = tk[1] - tk[0]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tk[4] - tk[0]; o[5] = tk[5] - tk[4];
     o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
@@ -280,7 +286,8 @@ int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv
                      (d->res2 ? px * r.cout : 0));
     sr::prof_begin(stream, r);
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * n, groups), dim3(NW * 64), lds, stream, p);
+  p.cogs = groups;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * n * groups), dim3(NW * 64), lds, stream, p);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("conv_bf16 launch");
   return SR_OK;
