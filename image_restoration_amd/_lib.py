@@ -141,8 +141,11 @@ SIGNATURES = {
                                           C.c_void_p]),
     'sr_conv4x4s2_weight_as_3x3_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_lrelu_bwd_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
-    'sr_bilinear2x_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.c_void_p]),
+    'sr_bilinear2x_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_void_p]),
+    'sr_cb16_add_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'sr_cb16_fork_bwd_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
     'sr_bilinear2x_bwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
     'sr_bn_lrelu_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -98,26 +98,28 @@ class UNetDiscriminatorSN(nn.Module):
         return A.FromCB8.apply(out, 1)
 
     def _forward_bf16(self, x):
+        """Same network on CB16 bf16 activations.  Neighbouring layers share memory passes (hip_autograd_bf16.py): the
+        encoder activations fork into (skip, pixel-unshuffled conv input) with one fused gradient pass, the first two skip
+        additions ride on the bilinear resampling, and conv8 / conv9 apply their producer's LeakyReLU derivative in the
+        data-gradient epilogue."""
         from .. import hip_autograd_bf16 as B
 
-        def conv(t, w, b, slope, nchw=False):
-            return B.ConvFn16.apply(t, w, b, slope, nchw)
-        x0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
-        x1 = conv(x0, self.conv1.weight(), None, 0.2)
-        x2 = conv(x1, self.conv2.weight(), None, 0.2)
-        x3 = conv(x2, self.conv3.weight(), None, 0.2)
-        x3 = B.Bilinear2xFn16.apply(x3)
-        x4 = conv(x3, self.conv4.weight(), None, 0.2)
-        if self.skip_connection:
-            x4 = B.AddFn16.apply(x4, x2)
-        x4 = B.Bilinear2xFn16.apply(x4)
-        x5 = conv(x4, self.conv5.weight(), None, 0.2)
-        if self.skip_connection:
-            x5 = B.AddFn16.apply(x5, x1)
-        x5 = B.Bilinear2xFn16.apply(x5)
-        x6 = conv(x5, self.conv6.weight(), None, 0.2)
-        if self.skip_connection:
+        def conv(t, w, b, slope, nchw=False, **kw):
+            return B.ConvFn16.apply(t, w, b, slope, nchw, kw.get('pre_unshuffled', False), kw.get('input_slope', 1.0),
+                                    kw.get('grad_premasked', False))
+        skip = self.skip_connection
+        x0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2, grad_premasked=True)
+        x0, u0 = B.SkipForkFn16.apply(x0, 0.2)
+        x1 = conv(u0, self.conv1.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
+        x1, u1 = B.SkipForkFn16.apply(x1, 0.2)
+        x2 = conv(u1, self.conv2.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
+        x2, u2 = B.SkipForkFn16.apply(x2, 0.2)
+        x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True)
+        x4 = conv(B.Bilinear2xFn16.apply(x3), self.conv4.weight(), None, 0.2)
+        x5 = conv(B.Bilinear2xFn16.apply(x4, x2 if skip else None), self.conv5.weight(), None, 0.2)
+        x6 = conv(B.Bilinear2xFn16.apply(x5, x1 if skip else None), self.conv6.weight(), None, 0.2)
+        if skip:
             x6 = B.AddFn16.apply(x6, x0)
-        out = conv(x6, self.conv7.weight(), None, 0.2)
-        out = conv(out, self.conv8.weight(), None, 0.2)
-        return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True)  # fp32 NCHW logits
+        out = conv(x6, self.conv7.weight(), None, 0.2, grad_premasked=True)
+        out = conv(out, self.conv8.weight(), None, 0.2, input_slope=0.2, grad_premasked=True)
+        return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True, input_slope=0.2)  # fp32 NCHW logits

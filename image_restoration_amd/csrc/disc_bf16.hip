@@ -40,6 +40,50 @@ __global__ void unshuffle2_kernel(const __bf16* __restrict__ src, long long src_
     *(bf16x8_t*)(dst + small) = *(const bf16x8_t*)(src + big);
 }
 
+// out = bf16(a + b), 8 elements per thread (skip connection in one pass)
+__global__ void add16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8_t x = ((const bf16x8_t*)a)[i], y = ((const bf16x8_t*)b)[i];
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)x[e] + (float)y[e]);
+  ((bf16x8_t*)out)[i] = o;
+}
+
+// Gradient of an encoder activation x that feeds a skip connection and, pixel-unshuffled, the next 4x4/s2 convolution:
+//   dz = lrelu'(x) * (g_skip + unshuffle^-1(g_u))   in one pass (g_skip may be null; mask may be null = no LeakyReLU);
+// the sum is rounded to bf16 before the mask, like the separate add and LeakyReLU-backward passes it replaces.
+__global__ void fork_bwd16_kernel(const __bf16* __restrict__ g_skip, const __bf16* __restrict__ g_u, const __bf16* __restrict__ mask,
+                                  __bf16* __restrict__ dz, float slope, int cblocks, int h, int w, long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int X = (int)(r % (2 * w));
+  r /= 2 * w;
+  const int Y = (int)(r % (2 * h));
+  r /= 2 * h;
+  const int cb = (int)(r % cblocks);
+  const long long n = r / cblocks;
+  const long long big = ((n * cblocks + cb) * 2 * h + Y) * (2LL * w) * 16 + (long long)X * 16 + half * 8;
+  const int par = (Y & 1) * 2 + (X & 1);
+  const long long small = (((n * 4 * cblocks + (long long)par * cblocks + cb) * h + (Y >> 1)) * w + (X >> 1)) * 16 + half * 8;
+  bf16x8_t s = *(const bf16x8_t*)(g_u + small);
+  if (g_skip) {
+    const bf16x8_t k = *(const bf16x8_t*)(g_skip + big);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = (__bf16)((float)s[e] + (float)k[e]);
+  }
+  if (mask) {
+    const bf16x8_t m = *(const bf16x8_t*)(mask + big);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (!((float)m[e] > 0.f)) s[e] = (__bf16)((float)s[e] * slope);
+  }
+  *(bf16x8_t*)(dz + big) = s;
+}
+
 // dz = gy * (y > 0 ? 1 : slope), 8 elements per thread
 __global__ void lrelu_bwd16_kernel(const __bf16* __restrict__ gy, const __bf16* __restrict__ y, __bf16* __restrict__ dz, float slope,
                                    long long n8) {
@@ -61,8 +105,10 @@ __device__ __forceinline__ void bil_taps16(int o, int size, int& i0, int& i1, fl
   w1 = s - (float)i0;
   w0 = 1.f - w1;
 }
-__global__ void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long long src_ns, __bf16* __restrict__ dst, long long dst_ns,
-                                        int cblocks, int h, int w, long long total) {
+// src2 != null: the interpolated tensor is bf16(src + src2) (a skip connection folded into the resampling pass)
+__global__ void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long long src_ns, const __bf16* __restrict__ src2,
+                                        long long src2_ns, __bf16* __restrict__ dst, long long dst_ns, int cblocks, int h, int w,
+                                        long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int half = (int)(i & 1);
@@ -77,9 +123,24 @@ __global__ void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long lon
   float wy0, wy1, wx0, wx1;
   bil_taps16(oy, h, y0, y1, wy0, wy1);
   bil_taps16(ox, w, x0, x1, wx0, wx1);
-  const __bf16* b = src + n * src_ns + (long long)cb * h * w * 16 + half * 8;
-  const bf16x8_t a00 = *(const bf16x8_t*)(b + ((long long)y0 * w + x0) * 16), a01 = *(const bf16x8_t*)(b + ((long long)y0 * w + x1) * 16),
-                 a10 = *(const bf16x8_t*)(b + ((long long)y1 * w + x0) * 16), a11 = *(const bf16x8_t*)(b + ((long long)y1 * w + x1) * 16);
+  const long long plane = (long long)cb * h * w * 16 + half * 8;
+  const long long o00 = ((long long)y0 * w + x0) * 16, o01 = ((long long)y0 * w + x1) * 16, o10 = ((long long)y1 * w + x0) * 16,
+                  o11 = ((long long)y1 * w + x1) * 16;
+  const __bf16* b = src + n * src_ns + plane;
+  bf16x8_t a00 = *(const bf16x8_t*)(b + o00), a01 = *(const bf16x8_t*)(b + o01), a10 = *(const bf16x8_t*)(b + o10),
+           a11 = *(const bf16x8_t*)(b + o11);
+  if (src2) {
+    const __bf16* c = src2 + n * src2_ns + plane;
+    const bf16x8_t c00 = *(const bf16x8_t*)(c + o00), c01 = *(const bf16x8_t*)(c + o01), c10 = *(const bf16x8_t*)(c + o10),
+                   c11 = *(const bf16x8_t*)(c + o11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a00[e] = (__bf16)((float)a00[e] + (float)c00[e]);
+      a01[e] = (__bf16)((float)a01[e] + (float)c01[e]);
+      a10[e] = (__bf16)((float)a10[e] + (float)c10[e]);
+      a11[e] = (__bf16)((float)a11[e] + (float)c11[e]);
+    }
+  }
   bf16x8_t o;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
@@ -157,6 +218,26 @@ extern "C" int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, 
   return SR_OK;
 }
 
+extern "C" int sr_cb16_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(a && b && out && n > 0 && n % 8 == 0, "sr_cb16_add_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(add16_kernel, dim3(nblk(n / 8)), dim3(256), 0, stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out,
+                     (long long)(n / 8));
+  SR_CHECK_LAUNCH("add16");
+  return SR_OK;
+}
+
+extern "C" int sr_cb16_fork_bwd_bf16(const void* g_skip, const void* g_u, const void* mask, void* dz, float slope, int n, int cblocks,
+                                     int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g_u && dz && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_fork_bwd_bf16: bad argument");
+  const long long total = (long long)n * cblocks * 2 * h * 2 * w * 2;
+  hipLaunchKernelGGL(fork_bwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g_skip, (const __bf16*)g_u,
+                     (const __bf16*)mask, (__bf16*)dz, slope, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("fork_bwd16");
+  return SR_OK;
+}
+
 extern "C" int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float slope, int64_t n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(gy && y && dz && n > 0 && n % 8 == 0, "sr_lrelu_bwd_bf16: n must be a positive multiple of 8");
@@ -166,13 +247,13 @@ extern "C" int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float 
   return SR_OK;
 }
 
-extern "C" int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_ns, void* dst, int64_t dst_ns, int n, int cblocks, int h, int w,
-                                      void* stream_) {
+extern "C" int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_ns, const void* src2, int64_t src2_ns, void* dst, int64_t dst_ns,
+                                      int n, int cblocks, int h, int w, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(src && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_fwd_bf16: bad argument");
   const long long total = (long long)n * cblocks * 2 * h * 2 * w * 2;
   hipLaunchKernelGGL(bilinear2x_fwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_ns,
-                     (__bf16*)dst, (long long)dst_ns, cblocks, h, w, total);
+                     (const __bf16*)src2, (long long)src2_ns, (__bf16*)dst, (long long)dst_ns, cblocks, h, w, total);
   SR_CHECK_LAUNCH("bilinear2x_fwd16");
   return SR_OK;
 }

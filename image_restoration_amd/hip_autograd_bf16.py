@@ -75,15 +75,23 @@ class ConvFn16(torch.autograd.Function):
                weights (csrc/disc_bf16.hip).  out_nchw=True returns fp32 NCHW (the logit map of the last layer).
     backward : sr_lrelu_bwd_bf16, data gradient = sr_conv3x3_bf16 with the transposed image (+ pixel shuffle back for 4x4),
                weight gradient = sr_conv3x3_wgrad_bf16 in fp32 (folded back to 4x4).
+
+    Three options let neighbouring layers share passes (the caller guarantees the stated conditions):
+      pre_unshuffled   the input of a 4x4 conv already is the pixel-unshuffled tensor (SkipForkFn16 made it); the returned
+                       gradient stays in that layout;
+      input_slope      != 1: the input is the LeakyReLU(input_slope) output of a layer with no other consumer, so the data
+                       gradient is multiplied by that LeakyReLU's derivative in the conv's epilogue (mask = the input) and
+                       the producer must be built with grad_premasked=True;
+      grad_premasked   the gradient arriving for this conv's output already carries its LeakyReLU derivative.
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_slope, out_nchw):
+    def forward(ctx, x, weight, bias, act_slope, out_nchw, pre_unshuffled=False, input_slope=1.0, grad_premasked=False):
         k = weight.size(2)
         weight = weight.detach().contiguous().float()
         cout, cin = weight.shape[:2]
         if k == 4:
-            src = _cb16(_unshuffle2(x.contiguous()))
+            src = _cb16(x.contiguous() if pre_unshuffled else _unshuffle2(x.contiguous()))
             w3 = _w4_as_w3(weight)
         elif k == 3:
             src, w3 = _cb16(x.contiguous()), weight
@@ -103,6 +111,8 @@ class ConvFn16(torch.autograd.Function):
         ctx.save_for_backward(src.buf, w3, saved_y)
         ctx.act_slope, ctx.has_bias, ctx.k, ctx.out_nchw = act_slope, bias is not None, k, out_nchw
         ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
+        ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked = pre_unshuffled, input_slope, grad_premasked
+        assert input_slope == 1.0 or k == 3, 'the input mask applies to 3x3 convs'
         return ret
 
     @staticmethod
@@ -116,7 +126,7 @@ class ConvFn16(torch.autograd.Function):
             dzc = H.nchw_to_cb16(gy.contiguous().float())
         else:
             gy = gy.contiguous()
-            if y is not None:
+            if y is not None and not ctx.grad_premasked:
                 dz = torch.empty_like(gy)
                 with torch.cuda.device(dev):
                     _lib.check(lib.sr_lrelu_bwd_bf16(gy.data_ptr(), y.data_ptr(), dz.data_ptr(), ctx.act_slope, gy.numel(),
@@ -127,29 +137,68 @@ class ConvFn16(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dw = db = None
         if need_x:
-            d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1)).buf  # roundup16(cin3) channels
-            dx = _unshuffle2(d, inverse=True) if ctx.k == 4 else d
+            if ctx.input_slope != 1.0:  # dL/d(pre-activation of the producer): mask = this conv's own input
+                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1), mask=src, mask_slope=ctx.input_slope).buf
+            else:
+                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1)).buf  # roundup16(cin3) channels
+            dx = _unshuffle2(d, inverse=True) if ctx.k == 4 and not ctx.pre_unshuffled else d
             if dx.size(1) != ctx.x_cb:
                 dx = dx[:, :ctx.x_cb].contiguous()
         if need_w or (need_b and ctx.has_bias):
             dw, db = H.conv3x3_wgrad_bf16(src, dzc, cout, cin3, want_bias=ctx.has_bias)
             if ctx.k == 4:
                 dw = _dw3_to_dw4(dw, ctx.cout, ctx.cin)
-        return dx, dw, (db if ctx.has_bias else None), None, None
+        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
+
+
+class SkipForkFn16(torch.autograd.Function):
+    """An encoder activation x = LeakyReLU(conv(..)) that feeds a skip connection and the next 4x4/s2 conv:
+    forward returns (x, pixel_unshuffle(x)) (sr_cb16_unshuffle2_bf16); backward folds the gradient sum, the way back
+    through the unshuffle and x's LeakyReLU derivative into one pass (sr_cb16_fork_bwd_bf16), so the conv that produced
+    x must be built with grad_premasked=True."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), _unshuffle2(x)
+
+    @staticmethod
+    def backward(ctx, g_skip, g_u):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        if g_u is None:  # the strided conv took no gradient (frozen network input): plain LeakyReLU backward of the skip
+            g_u = torch.zeros((x.size(0), 4 * x.size(1), x.size(2) // 2, x.size(3) // 2, 16), dtype=x.dtype, device=x.device)
+        n, cb, hh, ww, _ = x.shape
+        dz = torch.empty_like(x)
+        g_skip = g_skip.contiguous() if g_skip is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_cb16_fork_bwd_bf16(g_skip.data_ptr() if g_skip is not None else None, g_u.contiguous().data_ptr(),
+                                                 x.data_ptr(), dz.data_ptr(), ctx.slope, n, cb, hh // 2, ww // 2, _stream(x.device)),
+                       'sr_cb16_fork_bwd_bf16')
+        return dz, None
 
 
 class Bilinear2xFn16(torch.autograd.Function):
-    """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB16 (sr_bilinear2x_{fwd,bwd}_bf16)."""
+    """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB16 (sr_bilinear2x_{fwd,bwd}_bf16); with a
+    second input the resampled tensor is x + skip (the skip connection folded into the same pass)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip=None):
         lib = _lib.load()
         x = x.contiguous()
         n, cb, h, w, _ = x.shape
+        if skip is not None:
+            skip = skip.contiguous()
+            assert skip.shape == x.shape
         y = torch.empty((n, cb, 2 * h, 2 * w, 16), dtype=torch.bfloat16, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.sr_bilinear2x_fwd_bf16(x.data_ptr(), x[0].numel(), y.data_ptr(), y[0].numel(), n, cb, h, w,
-                                                  _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
+            _lib.check(lib.sr_bilinear2x_fwd_bf16(x.data_ptr(), x[0].numel(), skip.data_ptr() if skip is not None else None,
+                                                  skip[0].numel() if skip is not None else 0, y.data_ptr(), y[0].numel(), n, cb, h,
+                                                  w, _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
+        ctx.has_skip = skip is not None
         return y
 
     @staticmethod
@@ -161,21 +210,21 @@ class Bilinear2xFn16(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _lib.check(lib.sr_bilinear2x_bwd_bf16(g.data_ptr(), g[0].numel(), gx.data_ptr(), gx[0].numel(), n, cb, h2 // 2, w2 // 2,
                                                   _stream(g.device)), 'sr_bilinear2x_bwd_bf16')
-        return gx
+        return gx, (gx if ctx.has_skip else None)
 
 
 class AddFn16(torch.autograd.Function):
-    """a + b on CB16 (skip connections): a copy of a, then sr_cb16_axpby_bf16."""
+    """a + b on CB16 (skip connections) in one pass: sr_cb16_add_bf16."""
 
     @staticmethod
     def forward(ctx, a, b):
         lib = _lib.load()
-        out = a.clone()
-        b = b.contiguous()
-        n, cb, h, w, _ = out.shape
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
         with torch.cuda.device(a.device):
-            _lib.check(lib.sr_cb16_axpby_bf16(out.data_ptr(), out[0].numel(), b.data_ptr(), b[0].numel(), 1.0, 1.0, n, cb, h, w,
-                                              _stream(a.device)), 'sr_cb16_axpby_bf16')
+            _lib.check(lib.sr_cb16_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a.device)),
+                       'sr_cb16_add_bf16')
         return out
 
     @staticmethod

@@ -348,13 +348,21 @@ int sr_cb16_axpby_bf16(void* dst, int64_t dst_img_stride, const void* src, int64
  *                            cblocks = C/16; inverse = 1 is the adjoint, i.e. the data gradient's way back);
  *   sr_conv4x4s2_weight_as_3x3_f32: W[cout][cin][4][4] -> W'[cout][4 cin][3][3] (16 live taps of 36, the rest zero);
  *                            adjoint = 1 folds a 3x3 weight gradient back into w4.
- * sr_lrelu_bwd_bf16 / sr_bilinear2x_{fwd,bwd}_bf16 are the CB16 twins of the fp32 entry points above. */
+ * sr_lrelu_bwd_bf16 / sr_bilinear2x_{fwd,bwd}_bf16 are the CB16 twins of the fp32 entry points above;
+ * sr_bilinear2x_fwd_bf16 resamples bf16(src + src2) when src2 is given (a skip connection folded into the pass).
+ * sr_cb16_add_bf16: out = a + b over n contiguous elements (the skip connections, `x4 = x4 + x2` ...).
+ * sr_cb16_fork_bwd_bf16: gradient of an encoder activation x [N][C/16][2h][2w][16] that feeds a skip connection and,
+ *   pixel-unshuffled, the next 4x4/s2 convolution: dz = lrelu'(mask) * (g_skip + unshuffle^-1(g_u)) in one pass
+ *   (g_u [N][4C/16][h][w][16]; g_skip, mask optional; all tensors contiguous). */
 int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, void* dst, int64_t dst_img_stride, int n, int cblocks,
                             int h, int w, int inverse, void* stream);
 int sr_conv4x4s2_weight_as_3x3_f32(float* w4, float* w3, int cout, int cin, int adjoint, void* stream);
 int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float slope, int64_t n, void* stream);
-int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, void* dst, int64_t dst_img_stride, int n, int cblocks, int h,
-                           int w, void* stream);
+int sr_cb16_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int sr_cb16_fork_bwd_bf16(const void* g_skip, const void* g_u, const void* mask, void* dz, float slope, int n, int cblocks, int h,
+                          int w, void* stream);
+int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, const void* src2, int64_t src2_img_stride, void* dst,
+                           int64_t dst_img_stride, int n, int cblocks, int h, int w, void* stream);
 int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, int n, int cblocks, int h,
                            int w, void* stream);
 /* nn.BatchNorm2d + LeakyReLU of VGGStyleDiscriminator128 on CB16 activations (bf16 in / out; statistics, running

@@ -71,6 +71,61 @@ def test_bilinear2x_bf16(cuda):
     assert torch.all((dx - xr.grad).abs() <= xr.grad.abs() * 2 ** -8 + 1e-6)
 
 
+def test_shared_pass_ops_equal_their_separate_forms(cuda):
+    """The fused passes of the bf16 U-Net against the separate ops they replace, bit for bit: skip addition, bilinear
+    resampling of a sum, and the fork gradient (sum + way back through the pixel unshuffle + LeakyReLU derivative)."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, 3, 12, 20, 16, generator=g).to(torch.bfloat16).to(cuda)
+    b = torch.randn(2, 3, 12, 20, 16, generator=g).to(torch.bfloat16).to(cuda)
+    s = B.AddFn16.apply(a, b)
+    assert torch.equal(s, (a.float() + b.float()).to(torch.bfloat16))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = B.Bilinear2xFn16.apply(ar, br)
+    assert torch.equal(y, B.Bilinear2xFn16.apply(s))
+    gy = torch.randn(2, 3, 24, 40, 16, generator=g).to(torch.bfloat16).to(cuda)
+    y.backward(gy)
+    sr_ = s.clone().requires_grad_(True)
+    B.Bilinear2xFn16.apply(sr_).backward(gy)
+    assert torch.equal(ar.grad, sr_.grad) and torch.equal(br.grad, sr_.grad)
+    # fork: x [N, C/16, 2h, 2w, 16] -> (x, unshuffle(x)); backward of (g_skip, g_u)
+    x = torch.randn(2, 2, 8, 12, 16, generator=g).to(torch.bfloat16).to(cuda).requires_grad_(True)
+    xs, u = B.SkipForkFn16.apply(x, 0.2)
+    assert torch.equal(xs, x) and torch.equal(u, B._unshuffle2(x.detach()))
+    g_skip = torch.randn(2, 2, 8, 12, 16, generator=g).to(torch.bfloat16).to(cuda)
+    g_u = torch.randn(2, 8, 4, 6, 16, generator=g).to(torch.bfloat16).to(cuda)
+    torch.autograd.backward([xs, u], [g_skip, g_u])
+    total = (g_skip.float() + B._unshuffle2(g_u, inverse=True).float()).to(torch.bfloat16)
+    want = torch.where(x.detach().float() > 0, total, (total.float() * 0.2).to(torch.bfloat16))
+    assert torch.equal(x.grad, want)
+    x.grad = None
+    xs, u = B.SkipForkFn16.apply(x, 0.2)  # no skip consumer: only the strided conv sends a gradient
+    u.backward(g_u)
+    back = B._unshuffle2(g_u, inverse=True)
+    assert torch.equal(x.grad, torch.where(x.detach().float() > 0, back, (back.float() * 0.2).to(torch.bfloat16)))
+
+
+def test_conv_chain_with_epilogue_masks_matches_separate_passes(cuda):
+    """conv -> LeakyReLU -> conv with the first LeakyReLU's derivative applied in the second conv's data-gradient epilogue
+    (input_slope / grad_premasked) against the same chain with separate LeakyReLU-backward passes: identical forward,
+    gradients equal up to the one bf16 rounding the fused form saves."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 2, 16, 32, 16, generator=g).to(torch.bfloat16).to(cuda)
+    w1 = (torch.randn(32, 32, 3, 3, generator=g) * 0.08).to(cuda)
+    w2 = (torch.randn(16, 32, 3, 3, generator=g) * 0.08).to(cuda)
+    gy = torch.randn(2, 1, 16, 32, 16, generator=g).to(torch.bfloat16).to(cuda)
+    res = []
+    for fused in (False, True):
+        xr, a, b = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        h1 = B.ConvFn16.apply(xr, a, None, 0.2, False, False, 1.0, fused)
+        y = B.ConvFn16.apply(h1, b, None, 0.2, False, False, 0.2 if fused else 1.0, False)
+        y.backward(gy)
+        res.append((y.detach(), xr.grad, a.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][3], res[1][3])
+    for u, v in zip(res[0][1:3], res[1][1:3]):
+        d = (u.float() - v.float()).abs()
+        assert float(d.max()) <= 2 ** -6 * float(u.float().abs().max()) and float(d.norm() / u.float().norm()) < 4e-3
+
+
 @pytest.mark.parametrize('nf,h,w', [(16, 32, 48), (64, 64, 64)])
 def test_unet_bf16_vs_fp32_path(cuda, nf, h, w):
     """Logits and parameter gradients of the bf16 network against the fp32 HIP network (itself checked against the oracle in
