@@ -34,6 +34,8 @@ struct WgradReduce {  // wgrad_f32.hip: slab reduction shared with wgrad_bf16.hi
   float* db;
 };
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
+// up to 8 independent single-group rows with equal split counts in two launches; the rows share r[0].part / r[0].bpart
+int wgrad_reduce_rows(const WgradReduce* r, int nrows, hipStream_t stream);
 int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
                    float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream);
 // pack_net.hip: one-launch packing of every weight image of a network

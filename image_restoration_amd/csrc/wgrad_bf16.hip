@@ -822,6 +822,8 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
                      items.it[1], items.it[2], items.it[3], items.it[4], items.it[5], items.it[6], items.it[7]);
   if (prof) prof_end(stream);
   SR_CHECK_LAUNCH("wgrad_rdb_bf16 launch");
+  WgradReduce rows[8];  // all rows of the block reduce in two launches
+  int nr = 0;
   for (int ri = 0; ri < P.nrows; ++ri) {
     const RdbRow& r = P.rows[ri];
     const RdbItem& im = items.it[P.row_item[ri]];
@@ -853,10 +855,14 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
     rr.accumulate = accumulate;
     rr.dw = dparams[2 * (k - 1)];
     rr.db = bias ? dparams[2 * (k - 1) + 1] : nullptr;
-    int rc = wgrad_reduce(rr, stream);
-    if (rc) return rc;
+    if (!rr.dw) continue;  // frozen parameter
+    rows[nr++] = rr;
+    if (nr == 8) {
+      if (int rc = wgrad_reduce_rows(rows, nr, stream)) return rc;
+      nr = 0;
+    }
   }
-  return SR_OK;
+  return wgrad_reduce_rows(rows, nr, stream);
 }
 }  // namespace sr
 

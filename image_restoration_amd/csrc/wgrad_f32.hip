@@ -15,6 +15,8 @@
 // channel padding = the zero line; the head's nearest x2 upsample = src >> 1).
 // Partial sums leave the workgroup once (deterministic slab, no atomics); a second kernel sums
 // the slab over workgroups, applies the scale and scatters to OIHW.
+#include <algorithm>
+
 #include "sr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -227,12 +229,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 //          (coalesced 4 KiB rows, 8 independent loads in flight per lane) into part[sc][E].
 // Stage 2: one thread per element sums the SCH partials in fixed order, applies the scale and scatters to
 //          OIHW.  Element (pair, tap, g, lane, e): cout = ct*32 + 8g + 4(lane>>5) + e, cin position = it*32 + (lane&31).
-__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
-                                                            int e4, int splits, int chunk,
-                                                            const float* __restrict__ bslab, float* __restrict__ bpart,
-                                                            int nb, long long stride4, int bstride, int gi) {
-  // blockIdx.z = tile group of a multi-group launch: its slab / part blocks follow each other; bias per group row
-  const int grp = blockIdx.z, sch = gridDim.y;
+__device__ __forceinline__ void wgrad_reduce1_body(const float4* __restrict__ slab, float4* __restrict__ part, int e4, int splits,
+                                                   int chunk, const float* __restrict__ bslab, float* __restrict__ bpart, int nb,
+                                                   long long stride4, int bstride, int gi, int grp) {
+  // grp = tile group of a multi-group launch: its slab / part blocks follow each other; bias per group row
+  const int sch = gridDim.y;
   slab += (long long)grp * splits * stride4;
   part += (long long)grp * sch * e4;
   if (bslab) {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
     bpart += (long long)(grp / gi) * sch * nb;
   }
   const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, splits);
-  if (blockIdx.x == gridDim.x - 1) {  // the extra block column reduces the bias partials of this chunk
+  if (blockIdx.x == (unsigned)(e4 + 255) / 256) {  // the extra block column reduces the bias partials of this chunk
     if (bslab && grp % gi == 0 && (int)threadIdx.x < nb) {
       float b = 0.f;
       int s = s0;
@@ -285,6 +286,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
   part[(long long)blockIdx.y * e4 + i] = acc;
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
+                                                            int e4, int splits, int chunk,
+                                                            const float* __restrict__ bslab, float* __restrict__ bpart,
+                                                            int nb, long long stride4, int bstride, int gi) {
+  wgrad_reduce1_body(slab, part, e4, splits, chunk, bslab, bpart, nb, stride4, bstride, gi, blockIdx.z);
+}
+
+// Several independent reductions (the rows of a dense-block weight-gradient launch) in one launch: blockIdx.z = row.
+constexpr int kMaxReduceRows = 8;
+struct Reduce1Row {
+  const float4* slab;
+  float4* part;
+  const float* bslab;
+  float* bpart;
+  long long stride4;
+  int e4, nb, bstride;
+};
+struct Reduce1Rows {
+  Reduce1Row row[kMaxReduceRows];
+  int splits, chunk;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce1_rows_kernel(const Reduce1Rows p) {
+  const Reduce1Row& r = p.row[blockIdx.z];
+  if ((int)blockIdx.x > (r.e4 + 255) / 256) return;  // the grid is sized for the widest row (+ its bias column)
+  if ((int)blockIdx.x == (r.e4 + 255) / 256) {        // this row's bias column: same code path as the last column below
+    if (r.bslab && (int)threadIdx.x < r.nb) {
+      const int s0 = blockIdx.y * p.chunk, s1 = min(s0 + p.chunk, p.splits);
+      float b = 0.f;
+      for (int s = s0; s < s1; ++s) b += r.bslab[(long long)s * r.bstride + threadIdx.x];
+      r.bpart[blockIdx.y * r.nb + threadIdx.x] = b;
+    }
+    return;
+  }
+  wgrad_reduce1_body(r.slab, r.part, r.e4, p.splits, p.chunk, nullptr, nullptr, r.nb, r.stride4, r.bstride, 1, 0);
+}
+
 struct ReduceParams {
   const float* part;   // [sch][P*9*1024]
   const float* bpart;  // [sch][CT*32]
@@ -301,10 +338,10 @@ struct ReduceParams {
   int accumulate;
 };
 
-__global__ void wgrad_reduce2_kernel(const ReduceParams p) {
+__device__ __forceinline__ void wgrad_reduce2_body(const ReduceParams& p, int grp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_split = p.P * p.ntap * 1024;
-  const int grp = blockIdx.y, grow = grp / p.gi, gcol = grp - grow * p.gi;
+  const int grow = grp / p.gi, gcol = grp - grow * p.gi;
   const int cout_tile0 = p.cout_tile0 + grow * p.CT, cin_tile0 = p.cin_tile0 + gcol * p.IT;
   if (idx < per_split) {
     float s = 0.f;
@@ -339,6 +376,13 @@ __global__ void wgrad_reduce2_kernel(const ReduceParams p) {
     if (co < p.cout) p.db[co] = p.accumulate ? p.db[co] + s * p.scale : s * p.scale;
   }
 }
+
+__global__ void wgrad_reduce2_kernel(const ReduceParams p) { wgrad_reduce2_body(p, blockIdx.y); }
+
+struct Reduce2Rows {
+  ReduceParams row[kMaxReduceRows];
+};
+__global__ void wgrad_reduce2_rows_kernel(const Reduce2Rows p) { wgrad_reduce2_body(p.row[blockIdx.y], 0); }
 
 template <int CT, int IT, int R, int KS>
 constexpr int wgrad_lds_bytes() {
@@ -433,29 +477,8 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
 
 }  // namespace
 
-namespace sr {
-// Two-stage deterministic slab reduction + scatter to OIHW, shared by the fp32 and bf16 weight-gradient kernels
-// (both leave fp32 partial tiles in the 32x32 MFMA accumulator layout).  part holds 64 * P*ntap*1024 floats.
-int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
-  const int e4 = r.P * r.ntap * 256;
-  const int groups = r.groups > 0 ? r.groups : 1, gi = r.gi > 0 ? r.gi : 1;
-  int sch = (int)((r.splits + 63) / 64);
-  // part holds 64 * 4*9*1024 floats and bpart 64*64: shrink the stage-1 fan-out of multi-group launches to fit
-  int cap = (int)((size_t)64 * 4 * 9 * 1024 / ((size_t)groups * r.P * r.ntap * 1024));
-  const int bcap = 4096 / ((groups / gi) * r.CT * 32);
-  if (bcap < cap) cap = bcap;
-  if (cap < 1) {
-    set_error("wgrad_reduce: %d groups do not fit the partial buffers", groups);
-    return SR_EINVAL;
-  }
-  if (cap > 64) cap = 64;
-  if (sch > cap) sch = cap;
-  const int chunk = (int)((r.splits + sch - 1) / sch);
-  sch = (int)((r.splits + chunk - 1) / chunk);
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch, groups), dim3(256), 0, stream, (const float4*)r.slab,
-                     (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32,
-                     r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32, gi);
-  SR_CHECK_LAUNCH("wgrad_reduce1 launch");
+namespace {
+ReduceParams reduce2_params(const sr::WgradReduce& r, int sch, int gi) {
   ReduceParams rp;
   rp.part = r.part;
   rp.bpart = r.bslab ? r.bpart : nullptr;
@@ -482,8 +505,97 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   rp.seg_pad = r.seg_pad;
   rp.scale = r.scale;
   rp.accumulate = r.accumulate;
+  return rp;
+}
+}  // namespace
+
+namespace sr {
+// Two-stage deterministic slab reduction + scatter to OIHW, shared by the fp32 and bf16 weight-gradient kernels
+// (both leave fp32 partial tiles in the 32x32 MFMA accumulator layout).  part holds 64 * P*ntap*1024 floats.
+int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
+  const int e4 = r.P * r.ntap * 256;
+  const int groups = r.groups > 0 ? r.groups : 1, gi = r.gi > 0 ? r.gi : 1;
+  int sch = (int)((r.splits + 63) / 64);
+  // part holds 64 * 4*9*1024 floats and bpart 64*64: shrink the stage-1 fan-out of multi-group launches to fit
+  int cap = (int)((size_t)64 * 4 * 9 * 1024 / ((size_t)groups * r.P * r.ntap * 1024));
+  const int bcap = 4096 / ((groups / gi) * r.CT * 32);
+  if (bcap < cap) cap = bcap;
+  if (cap < 1) {
+    set_error("wgrad_reduce: %d groups do not fit the partial buffers", groups);
+    return SR_EINVAL;
+  }
+  if (cap > 64) cap = 64;
+  if (sch > cap) sch = cap;
+  const int chunk = (int)((r.splits + sch - 1) / sch);
+  sch = (int)((r.splits + chunk - 1) / chunk);
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((e4 + 255) / 256 + 1, sch, groups), dim3(256), 0, stream, (const float4*)r.slab,
+                     (float4*)r.part, e4, (int)r.splits, chunk, r.bslab, r.bpart, r.CT * 32,
+                     r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32, gi);
+  SR_CHECK_LAUNCH("wgrad_reduce1 launch");
+  const ReduceParams rp = reduce2_params(r, sch, gi);
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((r.P * r.ntap * 1024 + 255) / 256, groups), dim3(256), 0, stream, rp);
   SR_CHECK_LAUNCH("wgrad_reduce2 launch");
+  return SR_OK;
+}
+
+// The same reduction for up to kMaxReduceRows independent single-group rows (equal splits) in two launches instead of
+// 2 x nrows: rows[i].part / bpart are ignored, the rows share r[0].part / r[0].bpart, carved here.
+int wgrad_reduce_rows(const WgradReduce* r, int nrows, hipStream_t stream) {
+  if (nrows <= 0) return SR_OK;
+  if (nrows > kMaxReduceRows) {
+    set_error("wgrad_reduce_rows: %d rows > %d", nrows, kMaxReduceRows);
+    return SR_EINVAL;
+  }
+  int sum_p = 0, max_e4 = 0, max_e = 0;
+  for (int i = 0; i < nrows; ++i) {
+    if (r[i].splits != r[0].splits || r[i].groups > 1) {
+      set_error("wgrad_reduce_rows: rows must share the split count and be single-group");
+      return SR_EINVAL;
+    }
+    sum_p += r[i].P * r[i].ntap;
+    max_e4 = std::max(max_e4, r[i].P * r[i].ntap * 256);
+    max_e = std::max(max_e, r[i].P * r[i].ntap * 1024);
+  }
+  int sch = (int)((r[0].splits + 63) / 64);
+  int cap = (int)((size_t)64 * 4 * 9 / (size_t)sum_p);  // part holds 64 * 4*9*1024 floats, bpart 64*64
+  cap = std::min(cap, 4096 / (nrows * 32));
+  if (cap < 1) {
+    set_error("wgrad_reduce_rows: %d rows do not fit the partial buffers", nrows);
+    return SR_EINVAL;
+  }
+  sch = std::min(sch, std::min(cap, 64));
+  const int chunk = (int)((r[0].splits + sch - 1) / sch);
+  sch = (int)((r[0].splits + chunk - 1) / chunk);
+  Reduce1Rows s1;
+  Reduce2Rows s2;
+  s1.splits = (int)r[0].splits;
+  s1.chunk = chunk;
+  float* part = r[0].part;
+  float* bpart = r[0].bpart;
+  for (int i = 0; i < kMaxReduceRows; ++i) {
+    const WgradReduce& q = r[i < nrows ? i : 0];
+    WgradReduce w = q;
+    if (i < nrows) {
+      w.part = part;
+      w.bpart = bpart;
+      part += (size_t)sch * q.P * q.ntap * 1024;
+      bpart += (size_t)sch * q.CT * 32;
+    }
+    Reduce1Row& a = s1.row[i];
+    a.slab = (const float4*)w.slab;
+    a.part = (float4*)w.part;
+    a.bslab = w.bslab;
+    a.bpart = w.bpart;
+    a.e4 = i < nrows ? w.P * w.ntap * 256 : 0;
+    a.nb = w.CT * 32;
+    a.stride4 = w.split_stride ? w.split_stride / 4 : (long long)(w.P * w.ntap * 256);
+    a.bstride = w.bsplit_stride ? w.bsplit_stride : w.CT * 32;
+    s2.row[i] = reduce2_params(w, sch, 1);
+  }
+  hipLaunchKernelGGL(wgrad_reduce1_rows_kernel, dim3((max_e4 + 255) / 256 + 1, sch, nrows), dim3(256), 0, stream, s1);
+  SR_CHECK_LAUNCH("wgrad_reduce1_rows launch");
+  hipLaunchKernelGGL(wgrad_reduce2_rows_kernel, dim3((max_e + 255) / 256, nrows), dim3(256), 0, stream, s2);
+  SR_CHECK_LAUNCH("wgrad_reduce2_rows launch");
   return SR_OK;
 }
 }  // namespace sr
