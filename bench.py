@@ -264,6 +264,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
+    if args.groups:
+        from image_restoration_amd import _lib
+        _lib.check(_lib.load().sr_set_forward_groups(args.groups), 'sr_set_forward_groups')
     if args.mode == 'train':
         return train_mode(args, world, rank, dev, dist, backend)
     if args.mode == 'tiled':
@@ -271,9 +274,6 @@ def main():
 
     import image_restoration_amd as ira
     from image_restoration_amd.utils import synth
-    if args.groups:
-        from image_restoration_amd import _lib
-        _lib.check(_lib.load().sr_set_forward_groups(args.groups), 'sr_set_forward_groups')
     net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
     net.set_compute_dtype(args.dtype)
