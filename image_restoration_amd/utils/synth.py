@@ -133,3 +133,14 @@ def vgg128_state_dict(seed, num_in_ch=3, num_feat=64):
         else:
             sd[name] = np.array(0, dtype=np.int64)
     return sd
+
+
+def smooth_pairs(seed, n, size, scale=4):
+    """(lq, gt) batches with learnable structure for end-to-end training checks: gt = bicubic x8 enlargement of uniform
+    noise (smooth colour fields in [0, 1], [n, 3, size, size]), lq = its scale x scale box average."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(n, 3, size // 8 + 2, size // 8 + 2, generator=g)
+    gt = F.interpolate(low, scale_factor=8, mode='bicubic', align_corners=False)[:, :, 8:8 + size, 8:8 + size].clamp(0, 1)
+    return F.avg_pool2d(gt, scale), gt.contiguous()
