@@ -46,6 +46,27 @@ def test_conv_bf16_matches_float64_of_rounded_inputs(cin, cout, h, w, ups):
         assert float(out.buf[:, -1, :, :, cout % 16:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('cin,cout,n,h,w,tile', [
+    (64, 32, 8, 128, 128, '16 rows x 8 waves, 1 cout group'),
+    (64, 128, 8, 128, 128, '16 rows x 8 waves, 2 cout groups (cout-group-fastest XCD order)'),
+    (272, 128, 16, 128, 128, '32 rows x 8 waves (Cin > 256), 2 cout groups'),
+    (64, 96, 3, 112, 80, '16 rows x 4 waves, 3 cout groups of 32, ragged width'),
+    (32, 64, 5, 40, 200, '8 rows x 4 waves, ragged width'),
+])
+def test_conv_bf16_large_launch_tiles_match_fp32_kernel(cin, cout, n, h, w, tile):
+    """Every tile shape of the launch-size dispatch (csrc/conv_bf16.hip) against the fp32 HIP convolution (pinned to the
+    reference by the goldens) of the same bf16-rounded operands: the difference is the one bf16 rounding of the result."""
+    from image_restoration_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).float().cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3 * cin ** 0.5))).to(torch.bfloat16).float().cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    ref = ops.cb8_to_nchw(ops.conv3x3(ops.nchw_to_cb8(x), ops.PackedConv(wt, b), act_slope=0.2), cout)
+    got = ops.cb16_to_nchw(ops.conv3x3_bf16(ops.nchw_to_cb16(x), ops.PackedConvBF16(wt, b), act_slope=0.2), cout)
+    err = (got - ref).abs() - (ref.abs() * 2 ** -8 + 1e-4)
+    assert float(err.max()) <= 0, (tile, float((got - ref).abs().max()))
+
+
 def test_conv_bf16_concat_segments_residuals_and_nchw_out():
     """conv5-style launch: concat source [64 | 32 x4] read in place, two residuals, and the fp32 NCHW head."""
     from image_restoration_amd import hip_ops as ops
