@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ('res1', C.c_void_p), ('res1_img_stride', C.c_int64), ('beta1', C.c_float),
         ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float), ('res_cbn', C.c_int),
         ('out_h', C.c_int), ('out_w', C.c_int), ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
-        ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float),
+        ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float), ('s2_channels', C.c_int), ('s2_side', C.c_int),
     ]
 
 

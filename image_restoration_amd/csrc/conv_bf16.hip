@@ -37,6 +37,8 @@ struct ConvParamsH {
   int cout;
   int in_h, in_w, H, W, tiles_x, tiles_y;
   int cogs;         // cout groups (32*COT couts each)
+  int s2_cpb;       // S2 kernels: 16-channel blocks per parity class of the unshuffled operand
+  int s2_side;      // S2 kernels: 0 = parity of the input chunk decides the live taps, 1 = parity of the cout tile
   int src_shift;    // 1: nearest x2 upsample on the fly
   int mask_cbn;
   float slope, alpha, beta1, beta2, mask_slope;
@@ -48,7 +50,11 @@ __device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int COT, int PT, int NW, bool NCHW_OUT>
+// S2: the weights carry a 4x4/s2 convolution embedded in the 3x3 grid of a pixel-unshuffled operand: a parity class
+// (ry, rx) of channels has non-zero weights on 2x2 of the 9 taps only — rows {1-ry, 2-ry}, columns {1-rx, 2-rx} of the
+// forward image (input-channel parity), rows {ry, ry+1}, columns {rx, rx+1} of the data-gradient image (output-channel
+// parity) — and the loop issues those 4 taps (4/9 of the LDS reads and MFMAs; the skipped products are exact zeros).
+template <int COT, int PT, int NW, bool NCHW_OUT, bool S2 = false>
 __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
@@ -122,7 +128,29 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
   const int xlane = ((wave * PT) * XROW + j) * 32 + h * 16;
   const int wlane = j * 32 + h * 16;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int dy0, int dx0) {
+    if constexpr (S2) {
+      const char* xs = smem + buf * STAGE + xlane + (dy0 * XROW + dx0) * 32;
+      const char* ws = smem + buf * STAGE + XBYTES + wlane + (dy0 * 3 + dx0) * COT * 1024;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        bf16x8 bx[PT + 1], a[2][COT];
+#pragma unroll
+        for (int r = 0; r < PT + 1; ++r) bx[r] = *(const bf16x8*)(xs + (r * XROW + dx) * 32);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int c = 0; c < COT; ++c) a[dy][c] = *(const bf16x8*)(ws + ((dy * 3 + dx) * COT + c) * 1024);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < PT; ++r)
+              acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][c], bx[r + dy], acc[c][r], 0, 0, 0);
+      }
+      return;
+    }
     const char* xs = smem + buf * STAGE + xlane;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
 #pragma unroll
@@ -144,6 +172,13 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
             acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][c], bx[r + dy], acc[c][r], 0, 0, 0);
     }
   };
+  // S2: first live tap row / column of a parity class
+  auto s2_taps = [&](int chunk, int& dy0, int& dx0) {
+    const int par = (p.s2_side ? cog * (COT * 2) : chunk) / p.s2_cpb;
+    const int ry = par >> 1, rx = par & 1;
+    dy0 = p.s2_side ? ry : 1 - ry;
+    dx0 = p.s2_side ? rx : 1 - rx;
+  };
 
   const int nchunk = p.cin_blocks;
   long long tk[6] = {0, 0, 0, 0, 0, 0};
@@ -155,7 +190,9 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
     long long t0 = 0, t1 = 0;
     if (p.dbg) t0 = __builtin_readcyclecounter();
     if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
-    compute(c & 1);
+    int dy0 = 0, dx0 = 0;
+    if constexpr (S2) s2_taps(c, dy0, dx0);
+    compute(c & 1, dy0, dx0);
     if (p.dbg) t1 = __builtin_readcyclecounter();
     __syncthreads();
     if (p.dbg) {
@@ -263,11 +300,11 @@ constexpr int conv_bf16_lds() {
   return 2 * ((((NW * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
 }
 
-template <int COT, int PT, int NW, bool NCHW_OUT>
+template <int COT, int PT, int NW, bool NCHW_OUT, bool S2 = false>
 int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv3x3_desc* d) {
   constexpr int lds = conv_bf16_lds<COT, PT, NW>();
   static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-  auto kern = conv_bf16_kernel<COT, PT, NW, NCHW_OUT>;
+  auto kern = conv_bf16_kernel<COT, PT, NW, NCHW_OUT, S2>;
   if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   p.tiles_x = sr::cdiv(p.W, 32);
   p.tiles_y = sr::cdiv(p.H, NW * PT);
@@ -281,7 +318,7 @@ int launch_h(ConvParamsH p, int n, int groups, hipStream_t stream, const sr_conv
     r.h = p.H;
     r.w = p.W;
     const double px = (double)n * p.H * p.W;
-    r.flops = 2.0 * 9 * r.cin * r.cout * px;
+    r.flops = 2.0 * (S2 ? 4 : 9) * r.cin * r.cout * px;  // S2: the 16 taps of the 4x4 kernel = 4 per unshuffled channel
     r.bytes = 2.0 * ((double)n * p.in_h * p.in_w * r.cin + px * r.cout * (NCHW_OUT ? 2 : 1) + (d->res1 ? px * r.cout : 0) +
                      (d->res2 ? px * r.cout : 0));
     sr::prof_begin(stream, r);
@@ -313,6 +350,10 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 | (uintptr_t)d->res2 |
                 (uintptr_t)d->bpacked | (uintptr_t)d->mask_src) % 16 == 0,
                "sr_conv3x3_bf16: pointers must be 16-byte aligned");
+  SR_CHECK_ARG(d->s2_channels == 0 || (d->s2_channels > 0 && d->s2_channels % 64 == 0 && !d->upsample &&
+                                       (d->s2_side ? d->cout : d->cin_pad) == 4 * d->s2_channels),
+               "sr_conv3x3_bf16: s2_channels=%d must be a multiple of 64 and a quarter of the %s channels", d->s2_channels,
+               d->s2_side ? "output" : "input");
   ConvParamsH p = {};
   p.zero = sr::zero_line();
   p.in = (const char*)d->in;
@@ -373,6 +414,12 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   else
     tile = R4_W4;
   if (gc == 64) {
+    if (d->s2_channels > 0 && (tile == R16_W8 || tile == R32_W8)) {  // the strided convs of the discriminators
+      p.s2_cpb = d->s2_channels / 16;
+      p.s2_side = d->s2_side;
+      return tile == R16_W8 ? launch_h<2, 2, 8, false, true>(p, d->n, groups, stream, d)
+                            : launch_h<2, 4, 8, false, true>(p, d->n, groups, stream, d);
+    }
     switch (tile) {
       case R16_W8: return launch_h<2, 2, 8, false>(p, d->n, groups, stream, d);
       case R32_W8: return launch_h<2, 4, 8, false>(p, d->n, groups, stream, d);

@@ -98,6 +98,7 @@ class ConvFn16(torch.autograd.Function):
         else:
             raise NotImplementedError(f'kernel size {k}')
         pc = H.PackedConvBF16(w3, bias)
+        s2 = cin if (k == 4 and cin % 64 == 0) else 0  # lets the kernel skip the zero taps of the 3x3 embedding
         if out_nchw:
             assert act_slope == 1.0
             y = torch.empty((src.n, cout, src.h, src.w), dtype=torch.float32, device=x.device)
@@ -105,13 +106,13 @@ class ConvFn16(torch.autograd.Function):
             saved_y = None
             ret = y
         else:
-            out = H.conv3x3_bf16(src, pc, act_slope=act_slope)
+            out = H.conv3x3_bf16(src, pc, act_slope=act_slope, s2_channels=s2)
             saved_y = out.buf if act_slope != 1.0 else None
             ret = out.buf
         ctx.save_for_backward(src.buf, w3, saved_y)
         ctx.act_slope, ctx.has_bias, ctx.k, ctx.out_nchw = act_slope, bias is not None, k, out_nchw
         ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
-        ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked = pre_unshuffled, input_slope, grad_premasked
+        ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked, ctx.s2 = pre_unshuffled, input_slope, grad_premasked, s2
         assert input_slope == 1.0 or k == 3, 'the input mask applies to 3x3 convs'
         return ret
 
@@ -140,7 +141,7 @@ class ConvFn16(torch.autograd.Function):
             if ctx.input_slope != 1.0:  # dL/d(pre-activation of the producer): mask = this conv's own input
                 d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1), mask=src, mask_slope=ctx.input_slope).buf
             else:
-                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1)).buf  # roundup16(cin3) channels
+                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1), s2_channels=ctx.s2, s2_side=1).buf  # cin3 channels
             dx = _unshuffle2(d, inverse=True) if ctx.k == 4 and not ctx.pre_unshuffled else d
             if dx.size(1) != ctx.x_cb:
                 dx = dx[:, :ctx.x_cb].contiguous()

@@ -384,8 +384,9 @@ class PackedConvBF16:
 
 
 def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-                 beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2):
-    """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16."""
+                 beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0):
+    """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16.
+    s2_channels = C marks a 4x4/s2 conv carried on a pixel-unshuffled operand of 4C channels (zero taps are skipped)."""
     lib = _lib.load()
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
     H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
@@ -393,6 +394,7 @@ def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0,
     d.in_, d.in_img_stride, d.cin_pad, d.in_h, d.in_w = src.ptr, src.img_stride, pc.src_channels, src.h, src.w
     d.upsample = int(upsample)
     d.wpacked, d.bpacked, d.cout = pc.w.data_ptr(), (pc.b.data_ptr() if pc.b is not None else None), pc.cout
+    d.s2_channels, d.s2_side = s2_channels, s2_side
     if out_nchw is not None:
         assert out_nchw.is_contiguous() and out_nchw.dtype == torch.float32 and out_nchw.shape == (src.n, pc.cout, H, W)
         d.out, d.out_img_stride, d.out_nchw = out_nchw.data_ptr(), pc.cout * H * W, 1

@@ -118,6 +118,11 @@ typedef struct sr_conv3x3_desc {
                              the channel blocks [mask_cb0, mask_cb0+mask_cbn) of out (block 0 of
                              mask_src pairs with block mask_cb0 of out) */
   int64_t mask_img_stride; int mask_cb0, mask_cbn; float mask_slope;
+  int s2_channels;        /* sr_conv3x3_bf16 only, 0 = dense.  C > 0 (multiple of 64): the conv carries a 4x4/s2 convolution on
+                             a pixel-unshuffled operand of 4C channels (sr_conv4x4s2_weight_as_3x3_f32): per parity class of
+                             16-channel blocks only 2x2 of the 9 taps have non-zero weights and the kernel skips the rest
+                             (same result: the skipped products are exact zeros) */
+  int s2_side;            /* 0: the parity classes are the input channels (forward); 1: the output channels (data gradient) */
 } sr_conv3x3_desc;
 
 /* Fused 3x3 / stride 1 / pad 1 convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).

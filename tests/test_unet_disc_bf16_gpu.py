@@ -71,6 +71,25 @@ def test_bilinear2x_bf16(cuda):
     assert torch.all((dx - xr.grad).abs() <= xr.grad.abs() * 2 ** -8 + 1e-6)
 
 
+@pytest.mark.parametrize('c,cout,n,h,w', [(64, 128, 4, 128, 128), (128, 128, 8, 128, 128), (64, 64, 8, 128, 96)])
+def test_strided_conv_zero_tap_skipping_is_exact(cuda, c, cout, n, h, w):
+    """s2_channels lets the kernel skip the 20 all-zero taps (of 36) of a 4x4/s2 conv embedded in a 3x3 grid: forward and
+    data gradient must equal the dense walk over all taps bit for bit (launch sizes that reach the 8-wave tiles)."""
+    g = torch.Generator().manual_seed(c + cout)
+    u = torch.randn(n, 4 * c // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda)      # unshuffled input
+    w3 = B._w4_as_w3((torch.randn(cout, c, 4, 4, generator=g) * 0.05).to(cuda))
+    src = H.CB16(u)
+    pc = H.PackedConvBF16(w3, None)
+    dense = H.conv3x3_bf16(src, pc, act_slope=0.2).buf
+    assert float(dense.float().abs().max()) > 0
+    assert torch.equal(H.conv3x3_bf16(src, pc, act_slope=0.2, s2_channels=c).buf, dense)
+    dz = H.CB16(torch.randn(n, cout // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda))
+    pd = H.PackedConvBF16(w3, None, mode=1)
+    assert torch.equal(H.conv3x3_bf16(dz, pd, s2_channels=c, s2_side=1).buf, H.conv3x3_bf16(dz, pd).buf)
+    with pytest.raises(Exception):
+        H.conv3x3_bf16(src, pc, s2_channels=c // 2)  # not a quarter of the input channels
+
+
 def test_shared_pass_ops_equal_their_separate_forms(cuda):
     """The fused passes of the bf16 U-Net against the separate ops they replace, bit for bit: skip addition, bilinear
     resampling of a sum, and the fork gradient (sum + way back through the pixel unshuffle + LeakyReLU derivative)."""
