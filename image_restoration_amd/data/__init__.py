@@ -1,6 +1,7 @@
-"""Data side of the path: the rank-aware sampler of the reference, the paired image dataset with its crop / flip
+"""Data side of the path: the rank-aware sampler of the reference, the paired and LQ-only image datasets with the crop / flip
 augmentation and prefetchers, and a synthetic paired dataset for benchmarks / smoke training."""
 from .data_sampler import EnlargedSampler  # noqa: F401
 from .paired_image_dataset import PairedImageDataset  # noqa: F401
 from .prefetch_dataloader import CPUPrefetcher, CUDAPrefetcher  # noqa: F401
+from .single_image_dataset import SingleImageDataset  # noqa: F401
 from .synthetic_dataset import SyntheticPairedDataset  # noqa: F401

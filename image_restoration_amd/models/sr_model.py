@@ -140,7 +140,7 @@ class SRModel(BaseModel):
         metrics = val_opt.get('metrics')
         if metrics is not None:
             self.metric_results = {m: 0 for m in metrics.keys()}
-        idx = -1
+        idx, scored = -1, 0
         for idx, val_data in enumerate(dataloader):
             self.feed_data(val_data)
             self.test()
@@ -154,8 +154,10 @@ class SRModel(BaseModel):
                     osp.join(vis, dataset_name, f'{name}_{val_opt.get("suffix") or self.opt["name"]}.png')
                 os.makedirs(osp.dirname(path), exist_ok=True)
                 Image.fromarray(np.ascontiguousarray(tensor2img([out[0:1].cpu()], rgb2bgr=False))).save(path)
-            if metrics is not None:
-                assert gt is not None, 'validation metrics need ground truth'
+            if metrics is not None and gt is None and idx == 0:
+                self.logger.warning(f'{dataset_name} has no ground truth: images only, no metrics.')
+            if metrics is not None and gt is not None:
+                scored += 1
                 for mname, mopt in metrics.items():
                     mopt = dict(mopt)
                     mtype = mopt.pop('type')
@@ -169,9 +171,9 @@ class SRModel(BaseModel):
             if hasattr(self, 'gt'):
                 del self.gt
             del self.lq, self.output
-        if metrics is not None and idx >= 0:
+        if metrics is not None and scored > 0:
             for m in self.metric_results:
-                self.metric_results[m] /= (idx + 1)
+                self.metric_results[m] /= scored
             log = f'Validation {dataset_name}\n' + ''.join(f'\t # {m}: {v:.4f}\n' for m, v in self.metric_results.items())
             self.logger.info(log)
             if tb_logger:

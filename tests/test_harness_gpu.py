@@ -191,3 +191,43 @@ def test_train_on_png_folders_with_cuda_prefetch(cuda, tmp_path):
     model = train_pipeline(str(tmp_path), ['-opt', str(p)])
     assert model.optimizer_g.step_count == 5 and np.isfinite(model.get_current_log()['l_pix'])
     assert np.isfinite(model.metric_results['psnr']) and 0 < model.metric_results['ssim'] <= 1
+
+
+def test_test_entry_point_saves_images_and_metrics(cuda, tmp_path):
+    """python -m image_restoration_amd.test: a paired dataset (metrics + images) and an LQ-only dataset (images) through
+    SRModel.validation in test mode; the saved PNG equals the network output in the tensor2img convention."""
+    from PIL import Image
+    from image_restoration_amd.test import test_pipeline
+    from image_restoration_amd.utils.img_util import tensor2img
+    rng = np.random.default_rng(1)
+    (tmp_path / 'gt').mkdir(), (tmp_path / 'lq').mkdir()
+    for i in range(2):
+        gt = rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)
+        Image.fromarray(gt).save(tmp_path / 'gt' / f'p{i}.png')
+        Image.fromarray(gt.reshape(16, 4, 20, 4, 3).mean((1, 3)).astype(np.uint8)).save(tmp_path / 'lq' / f'p{i}.png')
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=16, num_block=1, num_grow_ch=8)
+    ck = tmp_path / 'net_g.pth'
+    torch.save({'params': {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(5, **cfg).items()}}, ck)
+    opt = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'options', 'test', 'ESRGAN',
+                                           'test_ESRGAN_x4.yml')))
+    opt['name'] = 'tiny_test'
+    opt['datasets'] = dict(test_1=dict(name='pairs', type='PairedImageDataset', dataroot_gt=str(tmp_path / 'gt'),
+                                       dataroot_lq=str(tmp_path / 'lq'), io_backend=dict(type='disk')),
+                           test_2=dict(name='lq_only', type='SingleImageDataset', dataroot_lq=str(tmp_path / 'lq'),
+                                       io_backend=dict(type='disk')))
+    opt['network_g'].update(num_feat=16, num_block=1, num_grow_ch=8)
+    opt['path'].update(pretrain_network_g=str(ck))
+    opt['val']['suffix'] = 'x4'
+    p = tmp_path / 'test.yml'
+    yaml.safe_dump(opt, open(p, 'w'))
+    model = test_pipeline(str(tmp_path), ['-opt', str(p)])
+    vis = tmp_path / 'results' / 'tiny_test' / 'visualization'
+    for ds in ('pairs', 'lq_only'):
+        assert sorted(os.listdir(vis / ds)) == ['p0_x4.png', 'p1_x4.png']
+    net = ira.build_network(dict(type='RRDBNet', **cfg)).to(cuda).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(5, **cfg).items()})
+    lq = torch.from_numpy(np.asarray(Image.open(tmp_path / 'lq' / 'p1.png')).transpose(2, 0, 1).astype(np.float32) / 255.)[None]
+    with torch.no_grad():
+        want = tensor2img([net(lq.to(cuda)).cpu()], rgb2bgr=False)
+    assert np.array_equal(np.asarray(Image.open(vis / 'lq_only' / 'p1_x4.png')), want)
+    assert not hasattr(model, 'optimizer_g')  # test mode builds no training state

@@ -38,6 +38,7 @@ def test_sampler_matches_reference_streams(golden):
     ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16.yml', True),
     ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml', True),
     ('options/test/ESRGAN/test_ESRGAN_x4_woGT.yml', False),
+    ('options/test/ESRGAN/test_ESRGAN_x4.yml', False),
 ])
 def test_option_files_parse_like_the_reference(path, is_train, tmp_path):
     opt = parse(os.path.join(ROOT, path), str(tmp_path), is_train=is_train)
@@ -50,6 +51,7 @@ def test_option_files_parse_like_the_reference(path, is_train, tmp_path):
         assert isinstance(opt['num_gpu'], int)  # 'auto' resolved
     else:
         assert opt['path']['results_root'] == os.path.join(str(tmp_path), 'results', opt['name'])
+        assert opt['datasets']['test_1']['phase'] == 'test' and opt['datasets']['test_1']['scale'] == 4
     assert 'network_g' in dict2str(opt)
     dbg = parse(os.path.join(ROOT, path), str(tmp_path), is_train=is_train, debug=True)
     assert dbg['name'].startswith('debug_')
