@@ -234,7 +234,7 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __re
 // ------------------------------------------------------------------ flat reductions / losses
 // mode 0: sum x ; 1: sum |x - t| (L1) ; 2: sum softplus(sign*(x - shift)) (BCE-with-logits vs target 1: sign=-1, 0: +1)
 // mode 3: sum sigmoid-based derivative d/dx of mode 2 (for the gradient through the mean of the other logits)
-// mode 4: sum x*t (dot product)
+// mode 4: sum x*t (dot product) ; 5: sum (x - t)^2 (MSE) ; 6: sum sqrt((x - t)^2 + sign) (Charbonnier, eps in `sign`)
 __device__ __forceinline__ float softplus(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256) void flat_reduce_kernel(const FlatRedParams p)
     else if (p.mode == 1) s += fabsf(v - p.t[i]);
     else if (p.mode == 2) s += softplus(p.sign * (v - shift));
     else if (p.mode == 4) s += v * p.t[i];
+    else if (p.mode == 5) s += (v - p.t[i]) * (v - p.t[i]);
+    else if (p.mode == 6) s += sqrtf((v - p.t[i]) * (v - p.t[i]) + p.sign);
     else s += p.sign * sigmoidf(p.sign * (v - shift));
   }
   s = block_sum(s, sh);
@@ -278,6 +280,15 @@ __global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restri
   if (i < n) {
     const float d = x[i] - t[i];
     dx[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * scale * g[0];
+  }
+}
+// MSE / Charbonnier backward: dx = g * scale * 2 (x - t)   or   g * scale * (x - t) / sqrt((x - t)^2 + eps)
+__global__ void pixel_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ g,
+                                 float scale, int kind, float eps, float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float d = x[i] - t[i];
+    dx[i] = (kind == 1 ? 2.f * d : d / sqrtf(d * d + eps)) * scale * g[0];
   }
 }
 // BCE backward wrt x: dx = g * scale * sign*sigmoid(sign*(x-shift))
@@ -752,6 +763,26 @@ extern "C" int sr_l1_loss_bwd_f32(const float* pred, const float* target, int64_
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, pred, target, gout, weight / (float)n, dpred,
                      (long long)n);
   SR_CHECK_LAUNCH("l1_bwd");
+  return SR_OK;
+}
+
+// kind 0: L1, 1: MSE, 2: Charbonnier(eps) — weight * mean(loss(pred - target)) and its gradient
+extern "C" int sr_pixel_loss_fwd_f32(const float* pred, const float* target, int64_t n, int kind, float eps, float weight,
+                                     float* loss, void* ws, size_t ws_bytes, void* stream) {
+  SR_CHECK_ARG(pred && target && loss && ws && n > 0 && ws_bytes >= sr_reduce_workspace_bytes(8) && kind >= 0 && kind <= 2,
+               "sr_pixel_loss_fwd_f32: bad argument");
+  return flat_reduce(pred, target, nullptr, n, kind == 0 ? 1 : kind == 1 ? 5 : 6, kind == 2 ? eps : 1.f, weight / (float)n, loss,
+                     (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int sr_pixel_loss_bwd_f32(const float* pred, const float* target, int64_t n, int kind, float eps, float weight,
+                                     const float* gout, float* dpred, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(pred && target && gout && dpred && n > 0 && kind >= 0 && kind <= 2, "sr_pixel_loss_bwd_f32: bad argument");
+  if (kind == 0) return sr_l1_loss_bwd_f32(pred, target, n, weight, gout, dpred, stream_);
+  hipLaunchKernelGGL(pixel_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, pred, target, gout, weight / (float)n, kind, eps, dpred,
+                     (long long)n);
+  SR_CHECK_LAUNCH("pixel_bwd");
   return SR_OK;
 }
 

@@ -223,6 +223,39 @@ class L1LossFn(torch.autograd.Function):
         return dp, None, None
 
 
+class PixelLossFn(torch.autograd.Function):
+    """weight * mean(criterion(pred - target)), criterion kind 1 = squared error, 2 = Charbonnier(eps)
+    (sr_pixel_loss_fwd_f32 / sr_pixel_loss_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, kind, eps):
+        lib = _lib.load()
+        pred, target = pred.contiguous(), target.contiguous()
+        dev = pred.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        wsb = lib.sr_reduce_workspace_bytes(8)
+        ws = scratch(dev, wsb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_pixel_loss_fwd_f32(pred.data_ptr(), target.data_ptr(), pred.numel(), kind, eps, weight,
+                                                 loss.data_ptr(), ws.data_ptr(), wsb, _stream(dev)), 'sr_pixel_loss_fwd_f32')
+        ctx.save_for_backward(pred, target)
+        ctx.args = (weight, kind, eps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, target = ctx.saved_tensors
+        weight, kind, eps = ctx.args
+        dev = pred.device
+        dp = torch.empty_like(pred)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_pixel_loss_bwd_f32(pred.data_ptr(), target.data_ptr(), pred.numel(), kind, eps, weight,
+                                                 g.contiguous().float().data_ptr(), dp.data_ptr(), _stream(dev)),
+                       'sr_pixel_loss_bwd_f32')
+        return dp, None, None, None, None
+
+
 class BCELogitsFn(torch.autograd.Function):
     """weight * BCEWithLogits(x - mean(other), target) with `other` optional (plain GAN loss when None).
 

@@ -3,10 +3,10 @@ import logging
 from copy import deepcopy
 
 from ..utils.registry import LOSS_REGISTRY
-from .losses import GANLoss, L1Loss  # noqa: F401
+from .losses import CharbonnierLoss, GANLoss, L1Loss, MSELoss  # noqa: F401
 from .perceptual_loss import PerceptualLoss  # noqa: F401
 
-__all__ = ['build_loss', 'L1Loss', 'GANLoss', 'PerceptualLoss']
+__all__ = ['build_loss', 'L1Loss', 'MSELoss', 'CharbonnierLoss', 'GANLoss', 'PerceptualLoss']
 
 
 def build_loss(opt):

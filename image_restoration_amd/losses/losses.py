@@ -33,6 +33,34 @@ class L1Loss(nn.Module):
 
 
 @LOSS_REGISTRY.register()
+class MSELoss(L1Loss):
+    """loss_weight * mean((pred - target)^2) (losses.py:165-191)."""
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        if weight is not None or self.reduction == 'none':
+            raise NotImplementedError('element-wise weights / reduction="none" are not implemented on the HIP path')
+        assert pred.shape == target.shape
+        scale = self.loss_weight * (pred.numel() if self.reduction == 'sum' else 1.0)
+        return A.PixelLossFn.apply(pred, target.detach(), float(scale), 1, 0.0)
+
+
+@LOSS_REGISTRY.register()
+class CharbonnierLoss(L1Loss):
+    """loss_weight * mean(sqrt((pred - target)^2 + eps)) (losses.py:194-227)."""
+
+    def __init__(self, loss_weight=1.0, reduction='mean', eps=1e-12):
+        super().__init__(loss_weight, reduction)
+        self.eps = eps
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        if weight is not None or self.reduction == 'none':
+            raise NotImplementedError('element-wise weights / reduction="none" are not implemented on the HIP path')
+        assert pred.shape == target.shape
+        scale = self.loss_weight * (pred.numel() if self.reduction == 'sum' else 1.0)
+        return A.PixelLossFn.apply(pred, target.detach(), float(scale), 2, float(self.eps))
+
+
+@LOSS_REGISTRY.register()
 class GANLoss(nn.Module):
     """GANLoss('vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight): loss_weight applies to generator
     calls only (is_disc=False), exactly as losses.py:460-461."""

@@ -248,6 +248,12 @@ int sr_l1_loss_fwd_f32(const float* pred, const float* target, int64_t n, float 
                        size_t ws_bytes, void* stream);
 int sr_l1_loss_bwd_f32(const float* pred, const float* target, int64_t n, float weight, const float* gout, float* dpred,
                        void* stream);
+/* The other pixel criteria of the reference on the same reduction: kind 0 = L1Loss, 1 = MSELoss (losses.py:165-191),
+ * 2 = CharbonnierLoss (:194-227, sqrt((pred - target)^2 + eps)); weight * mean over n elements and the gradient. */
+int sr_pixel_loss_fwd_f32(const float* pred, const float* target, int64_t n, int kind, float eps, float weight, float* loss,
+                          void* ws, size_t ws_bytes, void* stream);
+int sr_pixel_loss_bwd_f32(const float* pred, const float* target, int64_t n, int kind, float eps, float weight, const float* gout,
+                          float* dpred, void* stream);
 /* GANLoss('vanilla') = BCEWithLogitsLoss (losses.py:379-380,438-461) on z = x - shift[0] (shift = device scalar, the
  * batch mean of the other logits in the relativistic form, esrgan_model.py:40-41,67,71; NULL = 0):
  *   loss[0] = weight*mean(softplus(-z)) for target real, weight*mean(softplus(z)) for target fake;

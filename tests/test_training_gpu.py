@@ -108,6 +108,27 @@ def test_losses(cuda, golden):
         L1Loss(reduction='bad')
 
 
+def test_mse_and_charbonnier_pixel_losses(cuda):
+    """MSELoss / CharbonnierLoss (reference losses.py:165-227) against float64 torch expressions of their definitions
+    (value 1e-6 relative, gradient 1e-5 relative L2), through the registry like a yml `pixel_opt` would."""
+    from image_restoration_amd.losses import build_loss
+    g = torch.Generator().manual_seed(9)
+    pred, target = torch.rand(3, 3, 40, 52, generator=g), torch.rand(3, 3, 40, 52, generator=g)
+    for opt, ref_fn in ((dict(type='MSELoss', loss_weight=0.7), lambda d: 0.7 * (d ** 2).mean()),
+                        (dict(type='MSELoss', loss_weight=1.0, reduction='sum'), lambda d: (d ** 2).sum()),
+                        (dict(type='CharbonnierLoss', loss_weight=2.0, eps=1e-6), lambda d: 2.0 * torch.sqrt(d ** 2 + 1e-6).mean())):
+        p = pred.to(cuda).requires_grad_(True)
+        loss = build_loss(opt)(p, target.to(cuda))
+        loss.backward()
+        pr = pred.double().requires_grad_(True)
+        ref = ref_fn(pr - target.double())
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref)), opt
+        assert float((p.grad.cpu().double() - pr.grad).norm() / pr.grad.norm()) < 1e-5, opt
+    with pytest.raises(NotImplementedError):
+        build_loss(dict(type='MSELoss', reduction='none'))(pred.to(cuda), target.to(cuda))
+
+
 def _opt(model_type):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=1, manual_seed=0, is_train=True, dist=False, rank=0,
