@@ -6,7 +6,7 @@ network, clamp to [0,1], RGB->BGR HWC, *255 round (tensor2img, img_util.py:38-94
 sr_model.py:148).  Large frames go through the tiler (tiling.py).
 
     python -m image_restoration_amd.inference --input crop.png --output out.png --model_path net_g.pth \
-        [--num_block 23 --num_feat 64 --tile 512 --tile_pad 16]
+        [--num_block 23 --num_feat 64 --tile 512 --tile_pad 16 --compute_dtype fp32|bf16]
 """
 import argparse
 import glob
@@ -34,7 +34,8 @@ def imwrite_bgr(path, img):
 
 def load_generator(args, device):
     net = build_network(dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=args.scale, num_feat=args.num_feat,
-                             num_block=args.num_block, num_grow_ch=args.num_grow_ch))
+                             num_block=args.num_block, num_grow_ch=args.num_grow_ch,
+                             compute_dtype=getattr(args, 'compute_dtype', 'fp32')))
     if args.model_path:
         from .utils.checkpoint import load_generator_weights
         load_generator_weights(net, args.model_path, strict=True)  # BasicSR files and official ESRGAN key names
@@ -59,6 +60,8 @@ def main(argv=None):
     ap.add_argument('--num_grow_ch', type=int, default=32)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--tile_pad', type=int, default=16)
+    ap.add_argument('--compute_dtype', choices=('fp32', 'bf16'), default='fp32',
+                    help='fp32 = the reference arithmetic; bf16 = reduced-precision kernels (about 6x faster)')
     args = ap.parse_args(argv)
     net = load_generator(args, torch.device('cuda'))
     paths = sorted(glob.glob(os.path.join(args.input, '*'))) if os.path.isdir(args.input) else [args.input]

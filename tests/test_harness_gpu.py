@@ -47,6 +47,11 @@ def test_inference_script_roundtrip(cuda, golden, tmp_path):
     out = inference.imread_bgr(str(tmp_path / 'out.png'))
     diff = np.abs(out.astype(np.int32) - g['out_u8'].astype(np.int32))
     assert out.shape == (256, 256, 3) and diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    # the reduced-precision kernels behind the same script: a few grey levels at most on this 1-block net
+    inference.main(['--input', str(src), '--output', str(tmp_path / 'out16.png'), '--model_path', str(ck), '--num_feat', '32',
+                    '--num_block', '1', '--compute_dtype', 'bf16'])
+    d16 = np.abs(inference.imread_bgr(str(tmp_path / 'out16.png')).astype(np.int32) - g['out_u8'].astype(np.int32))
+    assert d16.max() <= 6 and d16.mean() < 0.5
 
 
 def test_train_entry_point_runs_saves_and_resumes(cuda, tmp_path):
