@@ -124,13 +124,13 @@ def train_mode(args, world, rank, dev, dist, backend):
     opt = parse(os.path.join(ROOT, 'training_config', 'train_rrdbnet_esrgan_x4_mi355x.yml'), ROOT, is_train=True)
     opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = world > 1, rank, world, 1
     opt['network_g']['compute_dtype'] = args.dtype
+    d_dtype = args.disc_dtype or args.dtype
     if args.disc == 'unet':
-        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True,
-                                compute_dtype=args.dtype)
+        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True, compute_dtype=d_dtype)
     elif args.lq != 32:
         raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
-    # the VGG discriminator stays fp32: at 128x128 inputs its layers are launch-bound and the bf16 form (compute_dtype: bf16,
-    # available) is slower (55 vs 47 ms per step measured)
+    else:
+        opt['network_d']['compute_dtype'] = d_dtype
     model = build_model(opt)
     lq = torch.from_numpy(synth.uniform_input(100 + rank, (args.batch, 3, args.lq, args.lq))).to(dev)
     gt = torch.from_numpy(synth.uniform_input(200 + rank, (args.batch, 3, 4 * args.lq, 4 * args.lq))).to(dev)
@@ -165,8 +165,8 @@ def train_mode(args, world, rank, dev, dist, backend):
             'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'fp32' else ('bf16 generator and discriminator, f32 master weights/optimiser' if args.disc == 'unet'
-                                                         else 'bf16 generator, f32 discriminator/optimiser'),
+            'dtype': 'f32' if args.dtype == 'fp32' else ('bf16 generator and discriminator, f32 master weights/optimiser'
+                                                         if d_dtype == 'bf16' else 'bf16 generator, f32 discriminator/optimiser'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
                                    % (args.batch, args.lq, args.lq), 'global_batch': world * args.batch,
@@ -244,6 +244,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='--mode train: batch per GPU')
     ap.add_argument('--lq', type=int, default=32, help='--mode train: LR patch size (gt = 4x)')
     ap.add_argument('--disc', choices=('vgg', 'unet'), default='vgg', help='--mode train: discriminator')
+    ap.add_argument('--disc-dtype', choices=('fp32', 'bf16'), default=None, help='--mode train: discriminator arithmetic (default: --dtype)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -924,12 +924,21 @@ extern "C" int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* strea
       const int gi = its / 4, rows_left = (cts - c0) / 2;
       // slab: groups * workgroups tiles of 8 pairs; partial buffers: groups * 8 pairs <= 256 and rows * 2 * 32 bias floats
       long long cap = (long long)(sc.wslab_bytes / ((size_t)8 * 9 * 1024 * sizeof(float))) / (strips_total > 0 ? strips_total : 1);
-      long long rows = cap / gi;
-      if (rows > 32 / gi) rows = 32 / gi;
-      if (rows < 1) rows = 1;
-      if (rows > rows_left) rows = rows_left;
-      int rc = launch_group<2, 4, 1, 1, 4>(d, p, c0, 0, (int)rows, gi, sc, d->dbias != nullptr, stream);
-      if (rc) return rc;
+      if (cap > 32) cap = 32;
+      SR_CHECK_ARG(cap >= 1, "sr_conv3x3_wgrad_bf16: slab too small for one tile group of %lld strips", strips_total);
+      long long rows = 1;
+      if (cap >= gi) {  // whole rows of cin groups per launch
+        rows = cap / gi;
+        if (rows > rows_left) rows = rows_left;
+        int rc = launch_group<2, 4, 1, 1, 4>(d, p, c0, 0, (int)rows, gi, sc, d->dbias != nullptr, stream);
+        if (rc) return rc;
+      } else {  // a very wide layer (the 2048-channel unshuffled input of the last strided conv): one row in cin chunks
+        for (int g0 = 0; g0 < gi; g0 += (int)cap) {
+          const int gn = gi - g0 < (int)cap ? gi - g0 : (int)cap;
+          int rc = launch_group<2, 4, 1, 1, 4>(d, p, c0, g0 * 4, 1, gn, sc, d->dbias != nullptr && g0 == 0, stream);
+          if (rc) return rc;
+        }
+      }
       i0 = gi * 4;
       // the remaining cin tiles of these rows, row by row
       for (int r = 0; r < rows; ++r) {

@@ -140,6 +140,7 @@ def test_rrdbnet_bf16_vs_reference_golden(golden):
     (48, 40, None, 0, 3, 9, 13, False),       # nothing aligned
     (512, 256, None, 0, 2, 8, 16, False),     # wide: 4 rows x 4 columns of 2x4 tile groups in one launch
     (288, 192, None, 0, 2, 8, 8, False),      # 3 cout rows x (2 batched columns + 1 odd cin tile)
+    (2048, 128, None, 0, 32, 4, 4, False),    # 16 cin groups x 32 strips: more tile groups than the slab holds, cin chunks
 ])
 def test_wgrad_bf16_matches_float64_of_rounded_inputs(cin, cout, first_seg, seg, n, h, w, ups):
     """dW, db in fp32 from bf16 x / dy: the products are exact in fp32, so the only error is fp32 summation order:

@@ -1,5 +1,5 @@
 """Times full ESRGANModel.optimize_parameters steps (G fwd/bwd, D, losses, both Adam steps, EMA) on synthetic batches.
-usage: python tools/perf_esrgan_step.py <yml> [batch] [lq_size] [iters] [compute_dtype] [disc: vgg|unet]"""
+usage: python tools/perf_esrgan_step.py <yml> [batch] [lq_size] [iters] [compute_dtype] [disc: vgg|unet] [disc compute_dtype]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,7 @@ LQ = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 DT = sys.argv[5] if len(sys.argv) > 5 else None
 DISC = sys.argv[6] if len(sys.argv) > 6 else None
+DDT = sys.argv[7] if len(sys.argv) > 7 else None
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 opt = parse(os.path.join(root, yml), root, is_train=True)
 opt['dist'] = False
@@ -22,6 +23,8 @@ if DT:
     opt['network_g']['compute_dtype'] = DT
 if DISC == 'unet':
     opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True)
+if DDT:
+    opt['network_d']['compute_dtype'] = DDT
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ)))
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ)))
