@@ -648,8 +648,19 @@ int run_groups(const sr_conv3x3_wgrad_desc* d, const WgradParams& p, int cin_pad
     const int nr = row_chunk(rows2 - r0, gi > 0 ? gi : 1, 4);
     const bool bias = want_bias && d->dbias != nullptr;
     if (gi > 0) {
-      int rc = launch_group<2, 2, 1, KT>(&dd, p, 2 * r0, 0, nr, gi, slab, bslab, bias, tm, stream);
-      if (rc) return rc;
+      // groups of one launch that fit the slab; a row wider than that (many cin tiles x many strips) goes out in cin chunks
+      const long long fit = (long long)(wslab_bytes / ((size_t)4 * 9 * 1024 * sizeof(float))) / strips_total;
+      SR_CHECK_ARG(fit >= 1, "sr_conv_wgrad: slab too small for one tile group of %lld strips", strips_total);
+      if (fit >= gi) {
+        int rc = launch_group<2, 2, 1, KT>(&dd, p, 2 * r0, 0, nr, gi, slab, bslab, bias, tm, stream);
+        if (rc) return rc;
+      } else {
+        for (int g0 = 0; g0 < gi; g0 += (int)fit) {  // nr == 1 here (row_chunk)
+          const int gn = gi - g0 < (int)fit ? gi - g0 : (int)fit;
+          int rc = launch_group<2, 2, 1, KT>(&dd, p, 2 * r0, 2 * g0, 1, gn, slab, bslab, bias && g0 == 0, tm, stream);
+          if (rc) return rc;
+        }
+      }
     }
     if (its % 2) {
       int rc = launch_group<2, 1, 1, KT>(&dd, p, 2 * r0, its - 1, nr, 1, slab, bslab, bias && gi == 0, tm, stream);

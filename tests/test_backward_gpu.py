@@ -58,6 +58,19 @@ def test_wgrad_kernel(cuda, cin, cout, first, seg, h, w, ups):
     assert _rel(db * 2, bs.grad.numpy()) < 1e-4
 
 
+def test_wgrad_kernel_wide_row_in_cin_chunks(cuda):
+    """A cout row whose cin tile groups x strips exceed the slab (512 channels, 32 images of 8 strips): the launch is cut
+    into cin chunks; result against fp32 CPU autograd."""
+    n, cin, cout, h, w = 32, 512, 64, 4, 256
+    x = torch.from_numpy(synth.signed_input(3, (n, cin, h, w)))
+    dy = torch.from_numpy(synth.signed_input(4, (n, cout, h, w)))
+    wt = torch.zeros((cout, cin, 3, 3), requires_grad=True)
+    bs = torch.zeros((cout,), requires_grad=True)
+    (F.conv2d(x, wt, bs, padding=1) * dy).sum().backward()
+    dw, db = H.conv3x3_wgrad(H.nchw_to_cb8(x.to(cuda)), H.nchw_to_cb8(dy.to(cuda)), cout, cin, cin, 0)
+    assert _rel(dw, wt.grad.numpy()) < 1e-4 and _rel(db, bs.grad.numpy()) < 1e-4
+
+
 def test_dgrad_kernel_with_mask_and_accumulate(cuda):
     """dX = conv_transpose(dY) through the forward kernel with mode-1 weights, + accumulate + LReLU mask."""
     n, cin, cout, h, w = 2, 96, 32, 9, 21
