@@ -46,8 +46,11 @@ def layer_names(vgg_type):
 class VGGFeatureExtractor(nn.Module):
 
     def __init__(self, layer_name_list, vgg_type='vgg19', use_input_norm=True, range_norm=False, requires_grad=False,
-                 remove_pooling=False, pooling_stride=2, weights_path=None):
+                 remove_pooling=False, pooling_stride=2, weights_path=None, compute_dtype='fp32'):
         super().__init__()
+        if compute_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype  # 'bf16': CB16 activations on the generator's bf16 conv kernels, fp32 features out
         if 'bn' in vgg_type:
             raise NotImplementedError('BatchNorm VGG variants are not on the HIP path')
         if pooling_stride != 2:
@@ -105,7 +108,15 @@ class VGGFeatureExtractor(nn.Module):
             raise _lib.SrHipError('VGGFeatureExtractor.forward runs only on a HIP device (no CPU fallback)')
         if self.range_norm or self.use_input_norm:
             x = A.ChannelAffineFn.apply(x, self.norm_a, self.norm_b)
-        feat = A.ToCB8.apply(x.contiguous().float())
+        if self.compute_dtype == 'bf16':
+            from .. import hip_autograd_bf16 as B
+            to_cb, from_cb, pool, lrelu = B.ToCB16.apply, B.FromCB16.apply, B.MaxPool2x2Fn16.apply, B.LReLUFn16.apply
+
+            def convf(t, w, b, slope):
+                return B.ConvFn16.apply(t, w, b, slope, False)
+        else:
+            to_cb, from_cb, pool, lrelu, convf = A.ToCB8.apply, A.FromCB8.apply, A.MaxPool2x2Fn.apply, A.LReLUFn.apply, A.ConvFn.apply
+        feat = to_cb(x.contiguous().float())
         want = set(self.layer_name_list)
         out = {}
         i = 0
@@ -115,20 +126,20 @@ class VGGFeatureExtractor(nn.Module):
                 conv = getattr(self.vgg_net, name)
                 relu_follows = i + 1 < len(self.names)
                 if name in want or not relu_follows:  # the conv output itself is a feature (e.g. conv5_4 before relu5_4)
-                    feat = A.ConvFn.apply(feat, conv.weight, conv.bias, 1.0)
-                    out[name] = A.FromCB8.apply(feat, conv.weight.size(0))
+                    feat = convf(feat, conv.weight, conv.bias, 1.0)
+                    out[name] = from_cb(feat, conv.weight.size(0))
                     if relu_follows:
-                        feat = A.LReLUFn.apply(feat, 0.0)
+                        feat = lrelu(feat, 0.0)
                 else:
-                    feat = A.ConvFn.apply(feat, conv.weight, conv.bias, 0.0)  # conv + ReLU fused
+                    feat = convf(feat, conv.weight, conv.bias, 0.0)  # conv + ReLU fused
                 if relu_follows:
                     i += 1
                     if self.names[i] in want:
-                        out[self.names[i]] = A.FromCB8.apply(feat, conv.weight.size(0))
+                        out[self.names[i]] = from_cb(feat, conv.weight.size(0))
             elif name.startswith('pool'):
                 if not self.remove_pooling:
-                    feat = A.MaxPool2x2Fn.apply(feat)
+                    feat = pool(feat)
                     if name in want:
-                        out[name] = A.FromCB8.apply(feat, _WIDTHS[int(name[4]) - 1])
+                        out[name] = from_cb(feat, _WIDTHS[int(name[4]) - 1])
             i += 1
         return {k: out[k] for k in self.layer_name_list if k in out}

@@ -84,6 +84,74 @@ __global__ void fork_bwd16_kernel(const __bf16* __restrict__ g_skip, const __bf1
   *(bf16x8_t*)(dz + big) = s;
 }
 
+// y = x > 0 ? x : slope * x, 8 elements per thread (a stand-alone ReLU after a feature that is wanted before it)
+__global__ void lrelu_fwd16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, float slope, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8_t a = ((const bf16x8_t*)x)[i];
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (float)a[e] > 0.f ? a[e] : (__bf16)((float)a[e] * slope);
+  ((bf16x8_t*)y)[i] = o;
+}
+
+// nn.MaxPool2d(2, 2) on CB16 (VGG feature extractor): [N][cb][h][w][16] -> [N][cb][h/2][w/2][16]; thread = 8 channels
+__global__ void maxpool16_fwd_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int oh = h / 2, ow = w / 2;
+  const int ox = (int)(r % ow);
+  r /= ow;
+  const int oy = (int)(r % oh);
+  const long long ncb = r / oh;
+  const __bf16* b = x + ((ncb * h + 2 * oy) * w + 2 * ox) * 16 + half * 8;
+  const bf16x8_t a00 = *(const bf16x8_t*)b, a01 = *(const bf16x8_t*)(b + 16), a10 = *(const bf16x8_t*)(b + (long long)w * 16),
+                 a11 = *(const bf16x8_t*)(b + (long long)w * 16 + 16);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(fmaxf((float)a00[e], (float)a01[e]), fmaxf((float)a10[e], (float)a11[e]));
+  *(bf16x8_t*)(y + ((ncb * oh + oy) * ow + ox) * 16 + half * 8) = o;
+}
+// the gradient of a window goes to its first maximum in scan order (torch's choice); thread per INPUT pixel half
+__global__ void maxpool16_bwd_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy, __bf16* __restrict__ dx, int h,
+                                     int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int xx = (int)(r % w);
+  r /= w;
+  const int yy = (int)(r % h);
+  const long long ncb = r / h;
+  const int oh = h / 2, ow = w / 2;
+  const int oy = yy >> 1, ox = xx >> 1;
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+  if (oy < oh && ox < ow) {
+    const __bf16* b = x + ((ncb * h + 2 * oy) * w + 2 * ox) * 16 + half * 8;
+    const bf16x8_t v[4] = {*(const bf16x8_t*)b, *(const bf16x8_t*)(b + 16), *(const bf16x8_t*)(b + (long long)w * 16),
+                           *(const bf16x8_t*)(b + (long long)w * 16 + 16)};
+    const bf16x8_t g = *(const bf16x8_t*)(dy + ((ncb * oh + oy) * ow + ox) * 16 + half * 8);
+    const int me = (yy & 1) * 2 + (xx & 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int arg = 0;
+      float m = (float)v[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if ((float)v[k][e] > m) {
+          m = (float)v[k][e];
+          arg = k;
+        }
+      if (arg == me) o[e] = g[e];
+    }
+  }
+  *(bf16x8_t*)(dx + ((ncb * h + yy) * w + xx) * 16 + half * 8) = o;
+}
+
 // dz = gy * (y > 0 ? 1 : slope), 8 elements per thread
 __global__ void lrelu_bwd16_kernel(const __bf16* __restrict__ gy, const __bf16* __restrict__ y, __bf16* __restrict__ dz, float slope,
                                    long long n8) {
@@ -215,6 +283,34 @@ extern "C" int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, 
   hipLaunchKernelGGL(unshuffle2_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_img_stride,
                      (__bf16*)dst, (long long)dst_img_stride, cblocks, h, w, inverse, total);
   SR_CHECK_LAUNCH("cb16_unshuffle2");
+  return SR_OK;
+}
+
+extern "C" int sr_lrelu_fwd_bf16(const void* x, void* y, float slope, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "sr_lrelu_fwd_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(lrelu_fwd16_kernel, dim3(nblk(n / 8)), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, slope,
+                     (long long)(n / 8));
+  SR_CHECK_LAUNCH("lrelu_fwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_maxpool2x2_fwd_bf16(const void* x, void* y, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && y && n > 0 && cblocks > 0 && h >= 2 && w >= 2, "sr_maxpool2x2_fwd_bf16: bad argument");
+  const long long total = (long long)n * cblocks * (h / 2) * (w / 2) * 2;
+  hipLaunchKernelGGL(maxpool16_fwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)x, (__bf16*)y, h, w, total);
+  SR_CHECK_LAUNCH("maxpool16_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_maxpool2x2_bwd_bf16(const void* x, const void* dy, void* dx, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && dy && dx && n > 0 && cblocks > 0 && h >= 2 && w >= 2, "sr_maxpool2x2_bwd_bf16: bad argument");
+  const long long total = (long long)n * cblocks * h * w * 2;
+  hipLaunchKernelGGL(maxpool16_bwd_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)dy, (__bf16*)dx,
+                     h, w, total);
+  SR_CHECK_LAUNCH("maxpool16_bwd");
   return SR_OK;
 }
 

@@ -233,6 +233,58 @@ class AddFn16(torch.autograd.Function):
         return g, g
 
 
+class MaxPool2x2Fn16(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=2, stride=2) on CB16 (sr_maxpool2x2_{fwd,bwd}_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, cb, h, w, _ = x.shape
+        y = torch.empty((n, cb, h // 2, w // 2, 16), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_maxpool2x2_fwd_bf16(x.data_ptr(), y.data_ptr(), n, cb, h, w, _stream(x.device)), 'sr_maxpool2x2_fwd_bf16')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        n, cb, h, w, _ = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_maxpool2x2_bwd_bf16(x.data_ptr(), g.contiguous().data_ptr(), dx.data_ptr(), n, cb, h, w,
+                                                  _stream(x.device)), 'sr_maxpool2x2_bwd_bf16')
+        return dx
+
+
+class LReLUFn16(torch.autograd.Function):
+    """Stand-alone LeakyReLU / ReLU on CB16 (sr_lrelu_fwd_bf16 / sr_lrelu_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_lrelu_fwd_bf16(x.data_ptr(), y.data_ptr(), slope, x.numel(), _stream(x.device)), 'sr_lrelu_fwd_bf16')
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        dz = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.sr_lrelu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), ctx.slope, g.numel(), _stream(g.device)),
+                       'sr_lrelu_bwd_bf16')
+        return dz, None
+
+
 class FromCB16(torch.autograd.Function):
     """CB16 bf16 -> NCHW fp32 with `channels` real channels; backward NCHW fp32 -> CB16 (pad channels zero)."""
 

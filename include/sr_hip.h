@@ -370,6 +370,10 @@ int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, void* dst, 
 int sr_conv4x4s2_weight_as_3x3_f32(float* w4, float* w3, int cout, int cin, int adjoint, void* stream);
 int sr_lrelu_bwd_bf16(const void* gy, const void* y, void* dz, float slope, int64_t n, void* stream);
 int sr_cb16_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* CB16 twins of sr_lrelu_fwd_f32 / sr_maxpool2x2_{fwd,bwd}_f32 (VGGFeatureExtractor with compute_dtype = 'bf16'). */
+int sr_lrelu_fwd_bf16(const void* x, void* y, float slope, int64_t n, void* stream);
+int sr_maxpool2x2_fwd_bf16(const void* x, void* y, int n, int cblocks, int h, int w, void* stream);
+int sr_maxpool2x2_bwd_bf16(const void* x, const void* dy, void* dx, int n, int cblocks, int h, int w, void* stream);
 int sr_cb16_fork_bwd_bf16(const void* g_skip, const void* g_u, const void* mask, void* dz, float slope, int n, int cblocks, int h,
                           int w, void* stream);
 int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, const void* src2, int64_t src2_img_stride, void* dst,

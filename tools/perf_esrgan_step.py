@@ -1,5 +1,5 @@
 """Times full ESRGANModel.optimize_parameters steps (G fwd/bwd, D, losses, both Adam steps, EMA) on synthetic batches.
-usage: python tools/perf_esrgan_step.py <yml> [batch] [lq_size] [iters] [compute_dtype] [disc: vgg|unet] [disc compute_dtype]"""
+usage: python tools/perf_esrgan_step.py <yml> [batch] [lq_size] [iters] [compute_dtype] [disc: vgg|unet] [disc compute_dtype] [perceptual compute_dtype]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +25,8 @@ if DISC == 'unet':
     opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True)
 if DDT:
     opt['network_d']['compute_dtype'] = DDT
+if len(sys.argv) > 8 and opt['train'].get('perceptual_opt'):
+    opt['train']['perceptual_opt']['compute_dtype'] = sys.argv[8]
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ)))
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ)))
