@@ -4,11 +4,9 @@ Every ``*_arch.py`` in this folder is imported at package import so its classes 
 themselves; ``build_network(opt)`` pops ``type`` and forwards the remaining keys as kwargs.
 """
 import importlib
-import logging
 import os
-from copy import deepcopy
 
-from ..utils.registry import ARCH_REGISTRY
+from ..utils.registry import ARCH_REGISTRY, instantiate
 
 __all__ = ['build_network']
 
@@ -19,8 +17,5 @@ _arch_modules = [
 
 
 def build_network(opt):
-    opt = deepcopy(opt)
-    network_type = opt.pop('type')
-    net = ARCH_REGISTRY.get(network_type)(**opt)
-    logging.getLogger('basicsr').info(f'Network [{net.__class__.__name__}] is created.')
-    return net
+    """``{type: RRDBNet, num_in_ch: 3, ..}`` -> nn.Module."""
+    return instantiate(ARCH_REGISTRY, opt, 'Network')

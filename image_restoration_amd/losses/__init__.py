@@ -1,8 +1,6 @@
-"""Loss registry + factory (reference: basicsr/losses/__init__.py:14-26)."""
-import logging
-from copy import deepcopy
-
-from ..utils.registry import LOSS_REGISTRY
+"""Losses of the path and their factory; every class files itself in LOSS_REGISTRY when its module is imported
+(counterpart of basicsr/losses/__init__.py:14-26)."""
+from ..utils.registry import LOSS_REGISTRY, instantiate
 from .losses import CharbonnierLoss, GANLoss, L1Loss, MSELoss  # noqa: F401
 from .perceptual_loss import PerceptualLoss  # noqa: F401
 
@@ -10,8 +8,5 @@ __all__ = ['build_loss', 'L1Loss', 'MSELoss', 'CharbonnierLoss', 'GANLoss', 'Per
 
 
 def build_loss(opt):
-    opt = deepcopy(opt)
-    loss_type = opt.pop('type')
-    loss = LOSS_REGISTRY.get(loss_type)(**opt)
-    logging.getLogger('basicsr').info(f'Loss [{loss.__class__.__name__}] is created.')
-    return loss
+    """``{type: L1Loss, loss_weight: ..}`` -> loss module."""
+    return instantiate(LOSS_REGISTRY, opt, 'Loss')

@@ -1,9 +1,6 @@
 """Model registry + factory (reference: basicsr/models/__init__.py:19-30): ``build_model(opt)`` picks
 ``opt['model_type']`` from MODEL_REGISTRY."""
-import logging
-from copy import deepcopy
-
-from ..utils.registry import MODEL_REGISTRY
+from ..utils.registry import MODEL_REGISTRY, instantiate
 from .sr_model import SRModel  # noqa: F401
 from .srgan_model import SRGANModel  # noqa: F401
 from .esrgan_model import ESRGANModel  # noqa: F401
@@ -12,7 +9,5 @@ __all__ = ['build_model']
 
 
 def build_model(opt):
-    opt = deepcopy(opt)
-    model = MODEL_REGISTRY.get(opt['model_type'])(opt)
-    logging.getLogger('basicsr').info(f'Model [{model.__class__.__name__}] is created.')
-    return model
+    """The whole option dict -> model of class ``opt['model_type']``."""
+    return instantiate(MODEL_REGISTRY, opt, 'Model', type_key='model_type', as_kwargs=False)

@@ -44,3 +44,16 @@ class Registry:
 
 ARCH_REGISTRY, MODEL_REGISTRY, LOSS_REGISTRY, DATASET_REGISTRY, METRIC_REGISTRY = (
     Registry(kind) for kind in ('arch', 'model', 'loss', 'dataset', 'metric'))
+
+
+def instantiate(registry, opt, what, type_key='type', as_kwargs=True):
+    """Shared body of build_network / build_loss / build_model: look ``opt[type_key]`` up in ``registry`` and construct it —
+    from the remaining keys as keyword arguments (architectures, losses) or from the whole option dict (models) — and log
+    the reference's "<what> [<class>] is created." line.  ``opt`` is not modified."""
+    import copy
+    import logging
+    conf = copy.deepcopy(opt)
+    cls = registry.get(conf.pop(type_key) if as_kwargs else conf[type_key])
+    obj = cls(**conf) if as_kwargs else cls(conf)
+    logging.getLogger('basicsr').info(f'{what} [{type(obj).__name__}] is created.')
+    return obj
