@@ -67,20 +67,22 @@ def cpu_baseline():
     sd = {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}
     cores = usable_cores()
     torch.set_num_threads(cores)
-    x = torch.from_numpy(synth.uniform_input(1234, (2, 3, TILE, TILE)))
+    x = torch.from_numpy(synth.uniform_input(1234, (4, 3, TILE, TILE)))
     with torch.no_grad():
         R.rrdbnet_forward(x[:1, :, :32, :32], sd, 4, CFG['num_block'])  # warm-up (thread pool, allocator)
-        best = float('inf')
-        t_all = time.perf_counter()
-        reps = 0
-        while reps < 3 and time.perf_counter() - t_all < 40:
-            t0 = time.perf_counter()
-            R.rrdbnet_forward(x, sd, 4, CFG['num_block'])
-            best = min(best, time.perf_counter() - t0)
-            reps += 1
-    return {'value': round(x.shape[0] / best, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'best of {reps} forwards of 2 of the 16 128x128 tiles, oracle/rrdbnet_ref.py (PyTorch CPU fp32, '
-                      f'{torch.get_num_threads()} threads)'}
+        best, best_b, t_all = 0.0, 0, time.perf_counter()
+        for b in (1, 2, 4):  # the CPU path's throughput depends on the batch it is given: report its best (about 12 s in all)
+            for _ in range(2):
+                if time.perf_counter() - t_all > 30:
+                    break
+                t0 = time.perf_counter()
+                R.rrdbnet_forward(x[:b], sd, 4, CFG['num_block'])
+                rate = b / (time.perf_counter() - t0)
+                if rate > best:
+                    best, best_b = rate, b
+    return {'value': round(best, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'best of 2 forwards each of 1, 2 and 4 of the 16 128x128 tiles (best: batch {best_b}), oracle/rrdbnet_ref.py '
+                      f'(PyTorch CPU fp32, {torch.get_num_threads()} threads)'}
 
 
 def kernel_rooflines(net, x):
