@@ -107,6 +107,9 @@ SIGNATURES = {
     'sr_l1_loss_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_pixel_loss_fwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p]),
+    'sr_gan_point_loss_fwd_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
+    'sr_gan_point_loss_bwd_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_pixel_loss_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     'sr_bce_logits_fwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p,

@@ -235,6 +235,8 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __re
 // mode 0: sum x ; 1: sum |x - t| (L1) ; 2: sum softplus(sign*(x - shift)) (BCE-with-logits vs target 1: sign=-1, 0: +1)
 // mode 3: sum sigmoid-based derivative d/dx of mode 2 (for the gradient through the mean of the other logits)
 // mode 4: sum x*t (dot product) ; 5: sum (x - t)^2 (MSE) ; 6: sum sqrt((x - t)^2 + sign) (Charbonnier, eps in `sign`)
+// mode 7: sum (x - sign)^2 (least-squares GAN, label in `sign`) ; 8: sum relu(1 + sign*x) (hinge) ;
+// mode 9: sum softplus(x) - sign*x (BCE-with-logits against the soft label `sign`)
 __device__ __forceinline__ float softplus(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
@@ -260,6 +262,9 @@ __global__ __launch_bounds__(256) void flat_reduce_kernel(const FlatRedParams p)
     else if (p.mode == 4) s += v * p.t[i];
     else if (p.mode == 5) s += (v - p.t[i]) * (v - p.t[i]);
     else if (p.mode == 6) s += sqrtf((v - p.t[i]) * (v - p.t[i]) + p.sign);
+    else if (p.mode == 7) s += (v - p.sign) * (v - p.sign);
+    else if (p.mode == 8) s += fmaxf(1.f + p.sign * v, 0.f);
+    else if (p.mode == 9) s += softplus(v) - p.sign * v;
     else s += p.sign * sigmoidf(p.sign * (v - shift));
   }
   s = block_sum(s, sh);
@@ -290,6 +295,21 @@ __global__ void pixel_bwd_kernel(const float* __restrict__ x, const float* __res
     const float d = x[i] - t[i];
     dx[i] = (kind == 1 ? 2.f * d : d / sqrtf(d * d + eps)) * scale * g[0];
   }
+}
+// point-wise GAN criteria, backward: kind 1 least squares 2 (x - c); 2 linear c; 3 softplus(c x): c sigmoid(c x);
+// 4 hinge relu(1 + c x): c [1 + c x > 0]; 5 BCE against the soft label c: sigmoid(x) - c
+__global__ void gan_point_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int kind, float c, float scale,
+                                     float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  float d;
+  if (kind == 1) d = 2.f * (v - c);
+  else if (kind == 2) d = c;
+  else if (kind == 3) d = c * sigmoidf(c * v);
+  else if (kind == 4) d = (1.f + c * v > 0.f) ? c : 0.f;
+  else d = sigmoidf(v) - c;
+  dx[i] = d * scale * g[0];
 }
 // BCE backward wrt x: dx = g * scale * sign*sigmoid(sign*(x-shift))
 __global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ g,
@@ -783,6 +803,29 @@ extern "C" int sr_pixel_loss_bwd_f32(const float* pred, const float* target, int
   hipLaunchKernelGGL(pixel_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, pred, target, gout, weight / (float)n, kind, eps, dpred,
                      (long long)n);
   SR_CHECK_LAUNCH("pixel_bwd");
+  return SR_OK;
+}
+
+// Point-wise GAN criteria of GANLoss (losses.py:379-461) other than the fused relativistic BCE: weight * mean f(x) with
+// kind 1: (x - c)^2 (lsgan, c = label); 2: c * x (wgan, c = -1 real / +1 fake; hinge generator c = -1);
+// 3: softplus(c x) (wgan_softplus, c = -1 real / +1 fake); 4: relu(1 + c x) (hinge discriminator, c = -1 real / +1 fake);
+// 5: softplus(x) - c x (vanilla against a soft label c)
+extern "C" int sr_gan_point_loss_fwd_f32(const float* x, int64_t n, int kind, float c, float weight, float* loss, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  SR_CHECK_ARG(x && loss && ws && n > 0 && kind >= 1 && kind <= 5 && ws_bytes >= sr_reduce_workspace_bytes(8),
+               "sr_gan_point_loss_fwd_f32: bad argument");
+  if (kind == 2) return flat_reduce(x, nullptr, nullptr, n, 0, 1.f, c * weight / (float)n, loss, (float*)ws, (hipStream_t)stream);
+  const int mode = kind == 1 ? 7 : kind == 3 ? 2 : kind == 4 ? 8 : 9;
+  return flat_reduce(x, nullptr, nullptr, n, mode, c, weight / (float)n, loss, (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int sr_gan_point_loss_bwd_f32(const float* x, int64_t n, int kind, float c, float weight, const float* gout, float* dx,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(x && gout && dx && n > 0 && kind >= 1 && kind <= 5, "sr_gan_point_loss_bwd_f32: bad argument");
+  hipLaunchKernelGGL(gan_point_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, gout, kind, c, weight / (float)n, dx,
+                     (long long)n);
+  SR_CHECK_LAUNCH("gan_point_bwd");
   return SR_OK;
 }
 

@@ -256,6 +256,36 @@ class PixelLossFn(torch.autograd.Function):
         return dp, None, None, None, None
 
 
+class GanPointLossFn(torch.autograd.Function):
+    """weight * mean f(x) for the point-wise GAN criteria (sr_gan_point_loss_{fwd,bwd}_f32; kinds in include/sr_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, kind, c, weight):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        dev = x.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        wsb = lib.sr_reduce_workspace_bytes(8)
+        ws = scratch(dev, wsb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_gan_point_loss_fwd_f32(x.data_ptr(), x.numel(), kind, c, weight, loss.data_ptr(), ws.data_ptr(), wsb,
+                                                     _stream(dev)), 'sr_gan_point_loss_fwd_f32')
+        ctx.save_for_backward(x)
+        ctx.args = (kind, c, weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        kind, c, weight = ctx.args
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sr_gan_point_loss_bwd_f32(x.data_ptr(), x.numel(), kind, c, weight, g.contiguous().float().data_ptr(),
+                                                     dx.data_ptr(), _stream(x.device)), 'sr_gan_point_loss_bwd_f32')
+        return dx, None, None, None
+
+
 class BCELogitsFn(torch.autograd.Function):
     """weight * BCEWithLogits(x - mean(other), target) with `other` optional (plain GAN loss when None).
 

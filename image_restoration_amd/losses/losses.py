@@ -62,23 +62,41 @@ class CharbonnierLoss(L1Loss):
 
 @LOSS_REGISTRY.register()
 class GANLoss(nn.Module):
-    """GANLoss('vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight): loss_weight applies to generator
-    calls only (is_disc=False), exactly as losses.py:460-461."""
+    """GANLoss(gan_type, real_label_val=1.0, fake_label_val=0.0, loss_weight) with gan_type 'vanilla' | 'lsgan' | 'wgan' |
+    'wgan_softplus' | 'hinge' (losses.py:360-461); loss_weight applies to generator calls only (is_disc=False), exactly as
+    losses.py:460-461.  'vanilla' with the hard labels 1 / 0 — every recipe of the reference — runs the fused relativistic
+    BCE reduction; the other criteria are one point-wise reduction each (sr_gan_point_loss_*)."""
+
+    _TYPES = ('vanilla', 'lsgan', 'wgan', 'wgan_softplus', 'hinge')
 
     def __init__(self, gan_type, real_label_val=1.0, fake_label_val=0.0, loss_weight=1.0):
         super().__init__()
-        if gan_type != 'vanilla':
+        if gan_type not in self._TYPES:
             raise NotImplementedError(f'GAN type {gan_type} is not implemented.')
-        if real_label_val != 1.0 or fake_label_val != 0.0:
-            raise NotImplementedError('only hard labels 1.0 / 0.0 are implemented on the HIP path')
         self.gan_type, self.loss_weight = gan_type, loss_weight
         self.real_label_val, self.fake_label_val = real_label_val, fake_label_val
+        self._hard = gan_type == 'vanilla' and real_label_val == 1.0 and fake_label_val == 0.0
 
     def forward(self, input, target_is_real, is_disc=False):
-        w = 1.0 if is_disc else self.loss_weight
-        return A.BCELogitsFn.apply(input, None, bool(target_is_real), float(w))
+        w = float(1.0 if is_disc else self.loss_weight)
+        real = bool(target_is_real)
+        if self._hard:
+            return A.BCELogitsFn.apply(input, None, real, w)
+        label = float(self.real_label_val if real else self.fake_label_val)
+        sign = -1.0 if real else 1.0
+        if self.gan_type == 'vanilla':        # BCE-with-logits against a soft label
+            return A.GanPointLossFn.apply(input, 5, label, w)
+        if self.gan_type == 'lsgan':
+            return A.GanPointLossFn.apply(input, 1, label, w)
+        if self.gan_type == 'wgan':
+            return A.GanPointLossFn.apply(input, 2, sign, w)
+        if self.gan_type == 'wgan_softplus':
+            return A.GanPointLossFn.apply(input, 3, sign, w)
+        # hinge: the discriminator sees relu(1 -/+ x), the generator -mean(x) whatever the target (losses.py:450-455)
+        return A.GanPointLossFn.apply(input, 4, sign, w) if is_disc else A.GanPointLossFn.apply(input, 2, -1.0, w)
 
     def relativistic(self, pred, other, target_is_real, is_disc=False):
-        """== self(pred - torch.mean(other), target_is_real, is_disc) in one fused reduction."""
-        w = 1.0 if is_disc else self.loss_weight
-        return A.BCELogitsFn.apply(pred, other, bool(target_is_real), float(w))
+        """== self(pred - torch.mean(other), target_is_real, is_disc); one fused reduction for the default criterion."""
+        if self._hard:
+            return A.BCELogitsFn.apply(pred, other, bool(target_is_real), float(1.0 if is_disc else self.loss_weight))
+        return self(pred - other.float().mean(), target_is_real, is_disc)

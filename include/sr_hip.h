@@ -254,6 +254,12 @@ int sr_pixel_loss_fwd_f32(const float* pred, const float* target, int64_t n, int
                           void* ws, size_t ws_bytes, void* stream);
 int sr_pixel_loss_bwd_f32(const float* pred, const float* target, int64_t n, int kind, float eps, float weight, const float* gout,
                           float* dpred, void* stream);
+/* The other criteria of GANLoss (losses.py:379-461; the default 'vanilla' with hard labels is sr_bce_logits_*): weight * mean f(x),
+ * kind 1 (x - c)^2 'lsgan' (c = label); 2 c*x 'wgan' / hinge generator (c = -1 real, +1 fake); 3 softplus(c*x) 'wgan_softplus';
+ * 4 relu(1 + c*x) 'hinge' discriminator; 5 softplus(x) - c*x = BCE-with-logits against a soft label c. */
+int sr_gan_point_loss_fwd_f32(const float* x, int64_t n, int kind, float c, float weight, float* loss, void* ws, size_t ws_bytes,
+                              void* stream);
+int sr_gan_point_loss_bwd_f32(const float* x, int64_t n, int kind, float c, float weight, const float* gout, float* dx, void* stream);
 /* GANLoss('vanilla') = BCEWithLogitsLoss (losses.py:379-380,438-461) on z = x - shift[0] (shift = device scalar, the
  * batch mean of the other logits in the relativistic form, esrgan_model.py:40-41,67,71; NULL = 0):
  *   loss[0] = weight*mean(softplus(-z)) for target real, weight*mean(softplus(z)) for target fake;

@@ -103,9 +103,47 @@ def test_losses(cuda, golden):
                     if rel:
                         assert _rel(b.grad, g[key + '_gb']) < 1e-5, key
     with pytest.raises(NotImplementedError):
-        GANLoss('lsgan')
+        GANLoss('ragan')
     with pytest.raises(ValueError):
         L1Loss(reduction='bad')
+
+
+def test_gan_loss_other_criteria(cuda):
+    """lsgan / wgan / wgan_softplus / hinge and soft-label vanilla (losses.py:379-461) against float64 torch expressions of the
+    reference's definitions, values and gradients, plain and in the relativistic form of esrgan_model.py:40-41."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(2)
+    a0, b0 = torch.randn(6, 1, 9, 7, generator=g) * 2, torch.randn(6, 1, 9, 7, generator=g)
+
+    def ref(kind, x, real, disc, rl, fl, w):
+        if kind == 'vanilla':
+            l = F.binary_cross_entropy_with_logits(x, torch.full_like(x, rl if real else fl))
+        elif kind == 'lsgan':
+            l = ((x - (rl if real else fl)) ** 2).mean()
+        elif kind == 'wgan':
+            l = -x.mean() if real else x.mean()
+        elif kind == 'wgan_softplus':
+            l = F.softplus(-x).mean() if real else F.softplus(x).mean()
+        else:
+            l = F.relu(1 + (-x if real else x)).mean() if disc else -x.mean()
+        return l if disc else l * w
+    for kind, rl, fl in (('vanilla', 0.9, 0.1), ('lsgan', 1.0, 0.0), ('lsgan', 0.8, 0.2), ('wgan', 1.0, 0.0), ('wgan_softplus', 1.0, 0.0),
+                         ('hinge', 1.0, 0.0)):
+        gan = GANLoss(kind, real_label_val=rl, fake_label_val=fl, loss_weight=0.3)
+        for real in (True, False):
+            for disc in (True, False):
+                for rel in (False, True):
+                    a, b = a0.to(cuda).requires_grad_(True), b0.to(cuda).requires_grad_(True)
+                    l = gan.relativistic(a, b, real, is_disc=disc) if rel else gan(a, real, is_disc=disc)
+                    l.backward()
+                    ar, br = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+                    lr = ref(kind, ar - br.mean() if rel else ar, real, disc, rl, fl, 0.3)
+                    lr.backward()
+                    key = (kind, rl, real, disc, rel)
+                    assert abs(float(l) - float(lr)) < 2e-6 * max(1.0, abs(float(lr))), key
+                    assert float((a.grad.cpu().double() - ar.grad).norm()) <= 1e-5 * float(ar.grad.norm()) + 1e-9, key
+                    if rel:
+                        assert float((b.grad.cpu().double() - br.grad).norm()) <= 1e-5 * float(br.grad.norm()) + 1e-9, key
 
 
 def test_mse_and_charbonnier_pixel_losses(cuda):
