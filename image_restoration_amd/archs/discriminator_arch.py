@@ -67,6 +67,8 @@ class LinearParams(nn.Module):
 class VGGStyleDiscriminator128(nn.Module):
     """VGGStyleDiscriminator128(num_in_ch, num_feat): [N, num_in_ch, 128, 128] -> [N, 1] logits."""
 
+    input_size = 128  # VGGStyleDiscriminator256 adds one 8nf -> 8nf stage (discriminator_arch.py:75-143)
+
     def __init__(self, num_in_ch, num_feat, compute_dtype='fp32'):
         super().__init__()
         nf = num_feat
@@ -80,7 +82,8 @@ class VGGStyleDiscriminator128(nn.Module):
         self.conv0_0 = Conv3x3Params(num_in_ch, nf, bias=True)
         self.conv0_1 = Conv3x3Params(nf, nf, bias=False, ksize=4)
         self.bn0_1 = BatchNormParams(nf)
-        widths = [(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)]
+        widths = [(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)] + ([(nf * 8, nf * 8)] if self.input_size == 256 else [])
+        self.num_stages = len(widths)
         for i, (ci, co) in enumerate(widths, start=1):
             setattr(self, f'conv{i}_0', Conv3x3Params(ci, co, bias=False))
             setattr(self, f'bn{i}_0', BatchNormParams(co))
@@ -90,15 +93,16 @@ class VGGStyleDiscriminator128(nn.Module):
         self.linear2 = LinearParams(100, 1)
 
     def forward(self, x):
-        assert x.size(2) == 128 and x.size(3) == 128, (f'Input spatial size must be 128x128, but received {x.size()}.')
+        sz = self.input_size
+        assert x.size(2) == sz and x.size(3) == sz, (f'Input spatial size must be {sz}x{sz}, but received {x.size()}.')
         if not x.is_cuda:
-            raise _lib.SrHipError('VGGStyleDiscriminator128.forward runs only on a HIP device (no CPU fallback)')
+            raise _lib.SrHipError(f'{type(self).__name__}.forward runs only on a HIP device (no CPU fallback)')
         if self.compute_dtype == 'bf16':
             return self._forward_bf16(x)
         feat = A.ToCB8.apply(x.contiguous().float())
         feat = A.ConvFn.apply(feat, self.conv0_0.weight, self.conv0_0.bias, 0.2)            # lrelu(conv0_0(x))
         feat = self.bn0_1.apply_lrelu(A.ConvFn.apply(feat, self.conv0_1.weight, None, 1.0), 0.2)  # 64x64
-        for i in range(1, 5):
+        for i in range(1, self.num_stages + 1):
             c0, b0 = getattr(self, f'conv{i}_0'), getattr(self, f'bn{i}_0')
             c1, b1 = getattr(self, f'conv{i}_1'), getattr(self, f'bn{i}_1')
             feat = b0.apply_lrelu(A.ConvFn.apply(feat, c0.weight, None, 1.0), 0.2)
@@ -115,10 +119,19 @@ class VGGStyleDiscriminator128(nn.Module):
             return B.ConvFn16.apply(t, p.weight, p.bias, slope, False)
         feat = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0_0, 0.2)                # lrelu(conv0_0(x))
         feat = self.bn0_1.apply_lrelu(conv(feat, self.conv0_1, 1.0), 0.2, bf16=True)           # 64x64
-        for i in range(1, 5):
+        for i in range(1, self.num_stages + 1):
             feat = getattr(self, f'bn{i}_0').apply_lrelu(conv(feat, getattr(self, f'conv{i}_0'), 1.0), 0.2, bf16=True)
             feat = getattr(self, f'bn{i}_1').apply_lrelu(conv(feat, getattr(self, f'conv{i}_1'), 1.0), 0.2, bf16=True)
         feat = B.FromCB16.apply(feat, self.num_feat * 8)                                        # fp32 NCHW for the linear head
         feat = feat.reshape(feat.size(0), -1)
         feat = A.LinearFn.apply(feat, self.linear1.weight, self.linear1.bias, 0.2)
         return A.LinearFn.apply(feat, self.linear2.weight, self.linear2.bias, 1.0)
+
+
+@ARCH_REGISTRY.register()
+class VGGStyleDiscriminator256(VGGStyleDiscriminator128):
+    """VGGStyleDiscriminator256(num_in_ch, num_feat): [N, num_in_ch, 256, 256] -> [N, 1] logits; the 128 network with a sixth
+    stage conv5_0 / bn5_0 / conv5_1 / bn5_1 (8nf -> 8nf) before the same linear head (discriminator_arch.py:75-143)."""
+
+    input_size = 256
+

@@ -85,8 +85,9 @@ def signed_input(seed, shape, scale=1.0):
     return ((np.random.default_rng(seed).random(shape, dtype=np.float32) * 2 - 1) * np.float32(scale)).astype(np.float32)
 
 
-def vgg128_param_shapes(num_in_ch, num_feat):
-    """(name, shape, kind) in state_dict order of VGGStyleDiscriminator128 (discriminator_arch.py:21-46)."""
+def vgg128_param_shapes(num_in_ch, num_feat, input_size=128):
+    """(name, shape, kind) in state_dict order of VGGStyleDiscriminator128 (discriminator_arch.py:21-46) or, with
+    input_size=256, VGGStyleDiscriminator256 (:75-120: one more 8nf -> 8nf stage)."""
     nf = num_feat
     out = []
 
@@ -102,7 +103,8 @@ def vgg128_param_shapes(num_in_ch, num_feat):
     conv('conv0_0', num_in_ch, nf, 3, True)
     conv('conv0_1', nf, nf, 4, False)
     bn('bn0_1', nf)
-    for i, (ci, co) in enumerate([(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)], start=1):
+    widths = [(nf, nf * 2), (nf * 2, nf * 4), (nf * 4, nf * 8), (nf * 8, nf * 8)] + ([(nf * 8, nf * 8)] if input_size == 256 else [])
+    for i, (ci, co) in enumerate(widths, start=1):
         conv(f'conv{i}_0', ci, co, 3, False)
         bn(f'bn{i}_0', co)
         conv(f'conv{i}_1', co, co, 4, False)
@@ -112,11 +114,11 @@ def vgg128_param_shapes(num_in_ch, num_feat):
     return out
 
 
-def vgg128_state_dict(seed, num_in_ch=3, num_feat=64):
-    """Deterministic VGGStyleDiscriminator128 state (non-trivial BN affine and running statistics)."""
+def vgg128_state_dict(seed, num_in_ch=3, num_feat=64, input_size=128):
+    """Deterministic VGGStyleDiscriminator128 / 256 state (non-trivial BN affine and running statistics)."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
-    for name, shape, kind in vgg128_param_shapes(num_in_ch, num_feat):
+    for name, shape, kind in vgg128_param_shapes(num_in_ch, num_feat, input_size):
         if kind == 'conv':
             fan_in = shape[1] * shape[2] * shape[3]
             sd[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(math.sqrt(2.0 / fan_in) * 0.7)).astype(np.float32)

@@ -18,14 +18,15 @@ def _bn(x, sd, name, train, momentum=0.1, eps=1e-5):
     return F.batch_norm(x, rm, rv, sd[f'{name}.weight'], sd[f'{name}.bias'], train, momentum, eps)
 
 
-def vgg128_forward(x, sd, train=True):
-    """VGGStyleDiscriminator128.forward (discriminator_arch.py:51-72).  `sd`: dict of tensors with the reference's
-    state_dict keys (running statistics are modified in place when train=True)."""
-    assert x.size(2) == 128 and x.size(3) == 128
+def vgg128_forward(x, sd, train=True, input_size=128):
+    """VGGStyleDiscriminator128.forward (discriminator_arch.py:51-72) and, with input_size=256, VGGStyleDiscriminator256.forward
+    (:122-143: one more stage).  `sd`: dict of tensors with the reference's state_dict keys (running statistics are modified in
+    place when train=True)."""
+    assert x.size(2) == input_size and x.size(3) == input_size
     lrelu = lambda t: F.leaky_relu(t, 0.2)
     feat = lrelu(F.conv2d(x, sd['conv0_0.weight'], sd['conv0_0.bias'], 1, 1))
     feat = lrelu(_bn(F.conv2d(feat, sd['conv0_1.weight'], None, 2, 1), sd, 'bn0_1', train))
-    for i in range(1, 5):
+    for i in range(1, 6 if input_size == 256 else 5):
         feat = lrelu(_bn(F.conv2d(feat, sd[f'conv{i}_0.weight'], None, 1, 1), sd, f'bn{i}_0', train))
         feat = lrelu(_bn(F.conv2d(feat, sd[f'conv{i}_1.weight'], None, 2, 1), sd, f'bn{i}_1', train))
     feat = feat.view(feat.size(0), -1)

@@ -91,6 +91,25 @@ def test_vgg_discriminator_oracle(golden):
         _close(D.vgg128_forward(x.detach(), sd, train=False), g['out_eval'], 1e-5)
 
 
+def test_vgg256_discriminator_oracle(golden):
+    """VGGStyleDiscriminator256 (one more stage) against the reference's own run (golden G-n; input regenerated from its seed)."""
+    from oracle import discriminator_ref as D
+    g = golden('g_n_vgg256')
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in synth.vgg128_state_dict(71, 3, 4, 256).items()}
+    for k in sd:
+        if sd[k].is_floating_point() and 'running' not in k:
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(synth.uniform_input(72, (2, 3, 256, 256))).requires_grad_(True)
+    out = D.vgg128_forward(x, sd, train=True, input_size=256)
+    _close(out, g['out_train'], 1e-5)
+    (out * torch.from_numpy(g['R'])).sum().backward()
+    _close(x.grad[0], g['grad_x0'], 1e-6)
+    _close(sd['conv5_1.weight'].grad, g['grad_conv5_1_weight'], 1e-5)
+    _close(sd['bn5_0.running_var'], g['buf_bn5_0_running_var'], 1e-6)
+    with torch.no_grad():
+        _close(D.vgg128_forward(x.detach(), sd, train=False, input_size=256), g['out_eval'], 1e-5)
+
+
 def test_loss_oracle(golden):
     from oracle import discriminator_ref as D
     g = golden('g_h_losses')

@@ -47,6 +47,32 @@ def test_vgg_discriminator_train_and_eval(cuda, golden):
         net(torch.zeros(1, 3, 64, 64, device=cuda))
 
 
+def test_vgg256_discriminator_train_and_eval(cuda, golden):
+    """VGGStyleDiscriminator256 on the HIP path against the reference's own run (golden G-n): logits, input gradient, every
+    parameter gradient, BatchNorm buffers, eval-mode logits; the input-size assertion."""
+    g = golden('g_n_vgg256')
+    net = ira.build_network(dict(type='VGGStyleDiscriminator256', num_in_ch=3, num_feat=4)).to(cuda).train()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.vgg128_state_dict(71, 3, 4, 256).items()}, strict=True)
+    x = torch.from_numpy(synth.uniform_input(72, (2, 3, 256, 256))).to(cuda).requires_grad_(True)
+    out = net(x)
+    assert _rel(out, g['out_train']) < 1e-4
+    (out * torch.from_numpy(g['R']).to(cuda)).sum().backward()
+    assert _rel(x.grad[0], g['grad_x0']) < 5e-4
+    for n, p in net.named_parameters():
+        assert _rel(p.grad, g['grad_' + n.replace('.', '_')]) < 5e-4, n
+    for n, b in net.named_buffers():
+        ref = g['buf_' + n.replace('.', '_')]
+        if n.endswith('num_batches_tracked'):
+            assert int(b) == int(ref)
+        else:
+            assert _rel(b, ref) < 1e-5, n
+    net.eval()
+    with torch.no_grad():
+        assert _rel(net(x.detach()), g['out_eval']) < 1e-4
+    with pytest.raises(AssertionError):
+        net(torch.zeros(1, 3, 128, 128, device=cuda))
+
+
 def test_vgg_gradient_quality_vs_float64(cuda, golden):
     """How close is close enough?  Run the oracle in float64 (ground truth) and in float32 (what the reference's CPU
     path computes) and require the HIP gradients to be no further from the truth than 4x the CPU-fp32 error, per

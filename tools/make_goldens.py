@@ -156,6 +156,27 @@ def g_g(ref):
     save('g_g_vgg128', **arrays)
 
 
+def g_n(ref):
+    """G-n: VGGStyleDiscriminator256(3, 4): train-mode fwd/bwd on [2,3,256,256] (input regenerated from its seed), BN buffers,
+    eval fwd; of dL/dx only the first image is stored."""
+    net = ref.VGGStyleDiscriminator256(3, 4)
+    net.load_state_dict(to_torch(synth.vgg128_state_dict(71, 3, 4, 256)), strict=True)
+    net.train()
+    x = torch.from_numpy(synth.uniform_input(72, (2, 3, 256, 256))).requires_grad_(True)
+    R = torch.from_numpy(synth.signed_input(73, (2, 1)))
+    out = net(x)
+    (out * R).sum().backward()
+    arrays = dict(R=R.numpy(), out_train=out.detach().numpy(), grad_x0=x.grad.numpy()[0])
+    for n, p in net.named_parameters():
+        arrays['grad_' + n.replace('.', '_')] = p.grad.numpy()
+    for n, b in net.named_buffers():
+        arrays['buf_' + n.replace('.', '_')] = b.detach().numpy()
+    net.eval()
+    with torch.no_grad():
+        arrays['out_eval'] = net(x.detach()).numpy()
+    save('g_n_vgg256', **arrays)
+
+
 def g_h(ref):
     """G-h: L1Loss / GANLoss(vanilla) values + input grads on fixed tensors; the docstring vectors of weighted_loss
     (loss_util.py:78-85)."""
@@ -326,7 +347,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():
