@@ -213,6 +213,39 @@ def g_h(ref):
     save('g_h_losses', **arrays)
 
 
+def g_o(ref):
+    """G-o: the other criteria of the reference on fixed tensors: MSELoss, CharbonnierLoss (mean / sum) and GANLoss with lsgan,
+    wgan, wgan_softplus, hinge and soft-label vanilla — values and input gradients, plain and with the mean of a second
+    tensor subtracted (the relativistic form of esrgan_model.py:40-41)."""
+    arrays = {}
+    pred0 = synth.uniform_input(81, (2, 3, 12, 20))
+    tgt = torch.from_numpy(synth.uniform_input(82, (2, 3, 12, 20)))
+    arrays.update(pix_pred=pred0, pix_target=tgt.numpy())
+    for key, crit in (('mse_mean', ref.MSELoss(loss_weight=0.7)), ('mse_sum', ref.MSELoss(loss_weight=1.0, reduction='sum')),
+                      ('charb_mean', ref.CharbonnierLoss(loss_weight=2.0, eps=1e-6)),
+                      ('charb_sum', ref.CharbonnierLoss(loss_weight=1.0, reduction='sum', eps=1e-12))):
+        pred = torch.from_numpy(pred0).requires_grad_(True)
+        loss = crit(pred, tgt)
+        loss.backward()
+        arrays[key + '_loss'], arrays[key + '_grad'] = loss.detach().numpy(), pred.grad.numpy()
+    a0, b0 = synth.signed_input(83, (3, 1, 6, 10), 2.5), synth.signed_input(84, (3, 1, 6, 10), 2.5)
+    arrays.update(gan_a=a0, gan_b=b0)
+    for kind, rl, fl in (('vanilla', 0.9, 0.1), ('lsgan', 1.0, 0.0), ('lsgan', 0.8, 0.2), ('wgan', 1.0, 0.0), ('wgan_softplus', 1.0, 0.0),
+                         ('hinge', 1.0, 0.0)):
+        gan = ref.GANLoss(kind, real_label_val=rl, fake_label_val=fl, loss_weight=0.3)
+        for real in (True, False):
+            for disc in (True, False):
+                for rel in (False, True):
+                    a, b = torch.from_numpy(a0).requires_grad_(True), torch.from_numpy(b0).requires_grad_(True)
+                    l = gan(a - torch.mean(b) if rel else a, real, is_disc=disc)
+                    l.backward()
+                    key = f'{kind}_{rl}_real{int(real)}_disc{int(disc)}_rel{int(rel)}'
+                    arrays[key + '_loss'], arrays[key + '_ga'] = l.detach().numpy(), a.grad.numpy().copy()
+                    if rel:
+                        arrays[key + '_gb'] = b.grad.numpy().copy()
+    save('g_o_losses2', **arrays)
+
+
 def _esrgan_opt(model_type, ema):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=0, manual_seed=0, is_train=True, dist=False, rank=0,
@@ -347,7 +380,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():

@@ -90,6 +90,7 @@ def load_reference():
         VGGStyleDiscriminator128=disc.VGGStyleDiscriminator128, VGGStyleDiscriminator256=disc.VGGStyleDiscriminator256,
         pixel_unshuffle=arch_util.pixel_unshuffle,
         L1Loss=loss_mod.L1Loss, GANLoss=loss_mod.GANLoss, l1_loss=loss_mod.l1_loss, loss_util=loss_util,
+        MSELoss=loss_mod.MSELoss, CharbonnierLoss=loss_mod.CharbonnierLoss,
         lr_scheduler=lr_sched, SRModel=sr_model.SRModel, SRGANModel=srgan_model.SRGANModel,
         ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network)
     b._sr_ns = ns
