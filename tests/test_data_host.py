@@ -91,6 +91,23 @@ def test_paired_random_crop_and_augment_geometry():
     assert mod_crop(gt[:79, :93], 4).shape == (76, 92, 3)
 
 
+def test_paired_random_crop_matches_the_reference(golden):
+    """Seeded paired_random_crop / mod_crop against the reference's own transforms.py (golden G-p): same windows for the same
+    Python random state, for single images and for lists."""
+    g = golden('g_p_crop')
+    lq, gt = _coord_pair(20, 24, 4)
+    lq, gt = lq.astype(np.float32), gt.astype(np.float32)
+    for seed in range(16):
+        random.seed(seed)
+        gg, ll = paired_random_crop(gt, lq, 32, 4)
+        assert np.array_equal(ll, g[f'lq_{seed}']) and np.array_equal(gg[::31, ::31], g[f'gt_corner_{seed}'])
+    random.seed(99)
+    gs, ls = paired_random_crop([gt, gt + 1], [lq, lq + 1], 16, 4)
+    assert np.array_equal(ls[0], g['list_lq0']) and np.array_equal(ls[1], g['list_lq1'])
+    assert np.array_equal(gs[1][::15, ::15], g['list_gt1_corner'])
+    assert tuple(g['mod_crop_shape']) == mod_crop(gt[:79, :93], 4).shape
+
+
 def test_paired_image_dataset_train_and_val(folders):
     gt_dir, lq_dir = folders
     base = dict(name='t', type='PairedImageDataset', dataroot_gt=gt_dir, dataroot_lq=lq_dir, filename_tmpl='{}x4',

@@ -246,6 +246,26 @@ def g_o(ref):
     save('g_o_losses2', **arrays)
 
 
+def g_p(ref):
+    """G-p: paired_random_crop / mod_crop of the reference's transforms.py (plain numpy + Python's random): for seeds 0..15 the
+    LQ / GT windows drawn from a coordinate-coded pair, single images and lists of two."""
+    import random
+    T = ref.transforms
+    yy, xx = np.meshgrid(np.arange(20), np.arange(24), indexing='ij')
+    lq = np.stack([yy, xx, (yy + xx) % 7], axis=2).astype(np.float32)
+    gt = lq.repeat(4, 0).repeat(4, 1)
+    arrays = {}
+    for seed in range(16):
+        random.seed(seed)
+        g, l = T.paired_random_crop(gt, lq, 32, 4)
+        arrays[f'lq_{seed}'], arrays[f'gt_corner_{seed}'] = l, g[::31, ::31].copy()
+    random.seed(99)
+    gs, ls = T.paired_random_crop([gt, gt + 1], [lq, lq + 1], 16, 4)
+    arrays.update(list_lq0=ls[0], list_lq1=ls[1], list_gt1_corner=gs[1][::15, ::15].copy())
+    arrays['mod_crop_shape'] = np.array(T.mod_crop(gt[:79, :93], 4).shape)
+    save('g_p_crop', **arrays)
+
+
 def _esrgan_opt(model_type, ema):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=0, manual_seed=0, is_train=True, dist=False, rank=0,
@@ -380,7 +400,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():

@@ -85,6 +85,20 @@ def load_reference():
     except Exception:  # pragma: no cover - optional
         sampler = None
 
+    transforms = None
+    try:  # paired_random_crop / mod_crop are plain numpy; the module's `import cv2` needs a name to bind (cv2 is not installed):
+        # an EMPTY placeholder module — the functions that call into cv2 (augment: cv2.flip) are never used through it
+        placeholder = 'cv2' not in sys.modules
+        if placeholder:
+            sys.modules['cv2'] = types.ModuleType('cv2')
+        try:
+            transforms = importlib.import_module('basicsr.data.transforms')
+        finally:
+            if placeholder:
+                del sys.modules['cv2']
+    except Exception:  # pragma: no cover - optional
+        transforms = None
+
     ns = types.SimpleNamespace(
         registry=registry, RRDBNet=rrdb.RRDBNet, RRDB=rrdb.RRDB, ResidualDenseBlock=rrdb.ResidualDenseBlock,
         VGGStyleDiscriminator128=disc.VGGStyleDiscriminator128, VGGStyleDiscriminator256=disc.VGGStyleDiscriminator256,
@@ -92,6 +106,6 @@ def load_reference():
         L1Loss=loss_mod.L1Loss, GANLoss=loss_mod.GANLoss, l1_loss=loss_mod.l1_loss, loss_util=loss_util,
         MSELoss=loss_mod.MSELoss, CharbonnierLoss=loss_mod.CharbonnierLoss,
         lr_scheduler=lr_sched, SRModel=sr_model.SRModel, SRGANModel=srgan_model.SRGANModel,
-        ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network)
+        ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network, transforms=transforms)
     b._sr_ns = ns
     return ns
