@@ -13,10 +13,11 @@ from ..utils.registry import METRIC_REGISTRY
 
 
 def _to_y(img):
-    # BT.601 luma of a BGR float image in [0, 255] (metric_util.to_y_channel -> bgr2ycbcr(y_only=True))
+    # BT.601 luma of a BGR float image in [0, 255] (metric_util.to_y_channel -> bgr2ycbcr(y_only=True)), with the reference's
+    # number formats: float32 input in [0, 1], float64 dot product, result stored as float32 in [0, 1], scaled back by 255
     img = img.astype(np.float32) / 255.
-    y = np.dot(img, [24.966, 128.553, 65.481]) + 16.0
-    return y[..., None]
+    y = ((np.dot(img, [24.966, 128.553, 65.481]) + 16.0) / 255.).astype(np.float32)
+    return y[..., None] * 255.
 
 
 @METRIC_REGISTRY.register()

@@ -179,3 +179,16 @@ def test_sharded_tiler_gathers_the_frame(world):
             assert np.array_equal(out, ref.numpy())
         else:
             assert out.dtype == np.uint8 and np.array_equal(out, quantise_u8(ref).numpy())
+
+
+def test_calculate_psnr_matches_the_reference(golden):
+    """calculate_psnr against the reference's own psnr_ssim.py (golden G-q): crop_border, HWC / CHW, RGB and y channel."""
+    from image_restoration_amd.metrics import calculate_psnr
+    g = golden('g_q_psnr')
+    a, b = g['img1'], g['img2']
+    for cb in (0, 4):
+        for y in (False, True):
+            assert abs(calculate_psnr(a, b, cb, 'HWC', y) - float(g[f'psnr_cb{cb}_y{int(y)}'])) < 1e-9
+            assert abs(calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), cb, 'CHW', y) - float(g[f'psnr_chw_cb{cb}_y{int(y)}'])) < 1e-9
+    assert calculate_psnr(a, a, 0) == float(g['psnr_same']) == float('inf')
+

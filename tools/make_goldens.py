@@ -266,6 +266,21 @@ def g_p(ref):
     save('g_p_crop', **arrays)
 
 
+def g_q(ref):
+    """G-q: calculate_psnr of the reference (psnr_ssim.py:8-46) on a fixed uint8 pair: crop_border 0 / 4, HWC / CHW, RGB and the
+    y channel (BT.601 conversion of matlab_functions.bgr2ycbcr), and the identical-image case."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-12, 13, a.shape), 0, 255).astype(np.uint8)
+    arrays = dict(img1=a, img2=b)
+    for cb in (0, 4):
+        for y in (False, True):
+            arrays[f'psnr_cb{cb}_y{int(y)}'] = np.float64(ref.calculate_psnr(a, b, cb, 'HWC', y))
+            arrays[f'psnr_chw_cb{cb}_y{int(y)}'] = np.float64(ref.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), cb, 'CHW', y))
+    arrays['psnr_same'] = np.float64(ref.calculate_psnr(a, a, 0))
+    save('g_q_psnr', **arrays)
+
+
 def _esrgan_opt(model_type, ema):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=0, manual_seed=0, is_train=True, dist=False, rank=0,
@@ -400,7 +415,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_q': g_q, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():

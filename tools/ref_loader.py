@@ -99,6 +99,21 @@ def load_reference():
     except Exception:  # pragma: no cover - optional
         transforms = None
 
+    psnr_mod = None
+    try:  # calculate_psnr and the y-channel conversion are plain numpy (same empty cv2 placeholder as above; calculate_ssim,
+        # which does call cv2, is not used)
+        metrics.__path__ = [os.path.join(CPR, 'basicsr', 'metrics')]
+        placeholder = 'cv2' not in sys.modules
+        if placeholder:
+            sys.modules['cv2'] = types.ModuleType('cv2')
+        try:
+            psnr_mod = importlib.import_module('basicsr.metrics.psnr_ssim')
+        finally:
+            if placeholder:
+                del sys.modules['cv2']
+    except Exception:  # pragma: no cover - optional
+        psnr_mod = None
+
     ns = types.SimpleNamespace(
         registry=registry, RRDBNet=rrdb.RRDBNet, RRDB=rrdb.RRDB, ResidualDenseBlock=rrdb.ResidualDenseBlock,
         VGGStyleDiscriminator128=disc.VGGStyleDiscriminator128, VGGStyleDiscriminator256=disc.VGGStyleDiscriminator256,
@@ -106,6 +121,7 @@ def load_reference():
         L1Loss=loss_mod.L1Loss, GANLoss=loss_mod.GANLoss, l1_loss=loss_mod.l1_loss, loss_util=loss_util,
         MSELoss=loss_mod.MSELoss, CharbonnierLoss=loss_mod.CharbonnierLoss,
         lr_scheduler=lr_sched, SRModel=sr_model.SRModel, SRGANModel=srgan_model.SRGANModel,
-        ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network, transforms=transforms)
+        ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network, transforms=transforms,
+        calculate_psnr=getattr(psnr_mod, 'calculate_psnr', None))
     b._sr_ns = ns
     return ns
