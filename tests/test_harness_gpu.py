@@ -151,7 +151,7 @@ def test_sr_model_validation_loop_device_metrics(cuda, tmp_path):
         ref['psnr_y'] += calculate_psnr(a, b, 4, test_y_channel=True) / 3
     assert abs(model.metric_results['psnr'] - ref['psnr']) < 1e-4
     assert abs(model.metric_results['ssim'] - ref['ssim']) < 2e-5
-    assert abs(model.metric_results['psnr_y'] - ref['psnr_y']) < 1e-9
+    assert abs(model.metric_results['psnr_y'] - ref['psnr_y']) < 1e-5  # float32 y-channel arithmetic of the reference, summed in a different order
     assert os.path.exists(os.path.join(str(tmp_path), 'img1', 'img1_7.png'))
 
 
