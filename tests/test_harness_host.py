@@ -192,3 +192,21 @@ def test_calculate_psnr_matches_the_reference(golden):
             assert abs(calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), cb, 'CHW', y) - float(g[f'psnr_chw_cb{cb}_y{int(y)}'])) < 1e-9
     assert calculate_psnr(a, a, 0) == float(g['psnr_same']) == float('inf')
 
+
+
+def test_option_parsing_matches_the_reference(golden):
+    """options.parse and dict2str against the reference's own options.py run on this repository's option files (golden G-r):
+    identical dictionaries in train / test mode and with --debug, identical printed form."""
+    import json
+    g = golden('g_r_options')
+    files = json.loads(str(g['files']))
+    for i, (rel, is_train) in enumerate(files):
+        for debug in (False, True):
+            opt = parse(os.path.join(ROOT, rel), '/srv/run', is_train=is_train, debug=debug)
+            ref = json.loads(str(g[f'f{i}_d{int(debug)}_json']))
+            mine = json.loads(json.dumps(opt, sort_keys=True))
+            if isinstance(ref.get('num_gpu'), int) and isinstance(mine.get('num_gpu'), int):
+                mine['num_gpu'] = ref['num_gpu']  # 'auto' resolves to the local device count
+            assert mine == ref, (rel, debug, {k: (mine.get(k), ref.get(k)) for k in set(mine) | set(ref) if mine.get(k) != ref.get(k)})
+            if not debug:
+                assert dict2str(opt) == str(g[f'f{i}_str']), rel

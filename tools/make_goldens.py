@@ -281,6 +281,24 @@ def g_q(ref):
     save('g_q_psnr', **arrays)
 
 
+def g_r(ref):
+    """G-r: the reference's options.parse (options.py:37-95) and dict2str on this repository's own option files, train / test
+    mode and --debug, with a fixed root path; stored as JSON text."""
+    import json
+    files = [('options/train/ESRGAN/train_ESRGAN_x4_synthetic.yml', True), ('options/train/ESRGAN/train_RRDBNet_PSNR_x4_folders.yml', True),
+             ('training_config/train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml', True), ('options/test/ESRGAN/test_ESRGAN_x4.yml', False),
+             ('options/test/ESRGAN/test_ESRGAN_x4_woGT.yml', False)]
+    arrays = {}
+    for i, (rel, is_train) in enumerate(files):
+        for debug in (False, True):
+            opt = ref.options.parse(os.path.join(ROOT, rel), '/srv/run', is_train=is_train, debug=debug)
+            arrays[f'f{i}_d{int(debug)}_json'] = np.array(json.dumps(opt, sort_keys=True))
+            if not debug:
+                arrays[f'f{i}_str'] = np.array(ref.options.dict2str(opt))
+    arrays['files'] = np.array(json.dumps(files))
+    save('g_r_options', **arrays)
+
+
 def _esrgan_opt(model_type, ema):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=0, manual_seed=0, is_train=True, dist=False, rank=0,
@@ -415,7 +433,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_q': g_q, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_q': g_q, 'g_r': g_r, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():

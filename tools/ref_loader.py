@@ -99,6 +99,13 @@ def load_reference():
     except Exception:  # pragma: no cover - optional
         transforms = None
 
+    options_mod = None
+    try:  # options.parse / dict2str: needs `set_random_seed` by name only
+        utils.set_random_seed = lambda seed: None
+        options_mod = importlib.import_module('basicsr.utils.options')
+    except Exception:  # pragma: no cover - optional
+        options_mod = None
+
     psnr_mod = None
     try:  # calculate_psnr and the y-channel conversion are plain numpy (same empty cv2 placeholder as above; calculate_ssim,
         # which does call cv2, is not used)
@@ -122,6 +129,6 @@ def load_reference():
         MSELoss=loss_mod.MSELoss, CharbonnierLoss=loss_mod.CharbonnierLoss,
         lr_scheduler=lr_sched, SRModel=sr_model.SRModel, SRGANModel=srgan_model.SRGANModel,
         ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network, transforms=transforms,
-        calculate_psnr=getattr(psnr_mod, 'calculate_psnr', None))
+        calculate_psnr=getattr(psnr_mod, 'calculate_psnr', None), options=options_mod)
     b._sr_ns = ns
     return ns
