@@ -175,3 +175,27 @@ def test_prefetchers_iterate_a_loader(folders):
                 sizes.append(b['lq'].shape[0])
                 assert b['gt'].shape[1:] == (3, 32, 32) and len(b['gt_path']) == b['lq'].shape[0]
             assert sizes == [2, 1]
+
+
+def test_path_pairing_matches_the_reference(golden, tmp_path):
+    """paired_paths_from_folder / _from_meta_info_file against the reference's data_util.py on the same file names (golden G-s).
+    Folder mode: the reference returns the pairs in os.scandir order (file-system dependent), this build sorts them — the
+    pairs themselves must be the same set; meta-info mode keeps the file's order in both."""
+    import json
+    g = golden('g_s_paths')
+    gt_dir, lq_dir = tmp_path / 'gt', tmp_path / 'lq'
+    gt_dir.mkdir(), lq_dir.mkdir()
+    for n in json.loads(str(g['names'])):
+        base, ext = os.path.splitext(n)
+        (gt_dir / n).write_bytes(b'')
+        (lq_dir / f'{base}x4{ext}').write_bytes(b'')
+
+    def rel(paths):
+        return [{k: os.path.relpath(v, str(tmp_path)) for k, v in d.items()} for d in paths]
+    mine = rel(paired_paths_from_folder([str(lq_dir), str(gt_dir)], ['lq', 'gt'], '{}x4'))
+    ref = json.loads(str(g['folder']))
+    key = lambda d: d['gt_path']
+    assert sorted(mine, key=key) == sorted(ref, key=key) and mine == sorted(mine, key=key)
+    meta = tmp_path / 'meta.txt'
+    meta.write_text('a9.png (480,480,3)\n0802.png (480,480,3)\n')
+    assert rel(paired_paths_from_meta_info_file([str(lq_dir), str(gt_dir)], ['lq', 'gt'], str(meta), '{}x4')) == json.loads(str(g['meta']))

@@ -299,6 +299,30 @@ def g_r(ref):
     save('g_r_options', **arrays)
 
 
+PAIR_NAMES = ['0801.png', '0802.png', 'a10.png', 'a9.png', 'b.PNG']
+
+
+def g_s(ref):
+    """G-s: paired_paths_from_folder / paired_paths_from_meta_info_file of the reference's data_util.py on a fixed set of file
+    names (empty files in a temporary tree), with a filename template; stored relative to the tree."""
+    import json
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        gt_dir, lq_dir = os.path.join(tmp, 'gt'), os.path.join(tmp, 'lq')
+        os.makedirs(gt_dir), os.makedirs(lq_dir)
+        for n in PAIR_NAMES:
+            base, ext = os.path.splitext(n)
+            open(os.path.join(gt_dir, n), 'w').close()
+            open(os.path.join(lq_dir, f'{base}x4{ext}'), 'w').close()
+        rel = lambda paths: [{k: os.path.relpath(v, tmp) for k, v in d.items()} for d in paths]
+        a = ref.data_util.paired_paths_from_folder([lq_dir, gt_dir], ['lq', 'gt'], '{}x4')
+        meta = os.path.join(tmp, 'meta.txt')
+        with open(meta, 'w') as f:
+            f.write('a9.png (480,480,3)\n0802.png (480,480,3)\n')
+        b = ref.data_util.paired_paths_from_meta_info_file([lq_dir, gt_dir], ['lq', 'gt'], meta, '{}x4')
+    save('g_s_paths', folder=np.array(json.dumps(rel(a))), meta=np.array(json.dumps(rel(b))), names=np.array(json.dumps(PAIR_NAMES)))
+
+
 def _esrgan_opt(model_type, ema):
     from collections import OrderedDict as OD
     opt = OD(name='golden', model_type=model_type, scale=4, num_gpu=0, manual_seed=0, is_train=True, dist=False, rank=0,
@@ -433,7 +457,7 @@ def g_m(ref):
     save('g_m_sampler', **arrays)
 
 
-ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_q': g_q, 'g_r': g_r, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
+ALL = {'g_m': g_m, 'g_k': g_k, 'g_g': g_g, 'g_n': g_n, 'g_o': g_o, 'g_p': g_p, 'g_q': g_q, 'g_r': g_r, 'g_s': g_s, 'g_h': g_h, 'g_i': g_i, 'g_j': g_j, 'g_a': g_a, 'g_c': g_c, 'g_d': g_d, 'g_e': g_e, 'g_f': g_f, 'g_l': g_l}
 
 
 def main():

@@ -99,6 +99,22 @@ def load_reference():
     except Exception:  # pragma: no cover - optional
         transforms = None
 
+    data_util = None
+    try:  # paired_paths_from_folder / _from_meta_info_file are plain Python over scandir (misc.py); same cv2 placeholder
+        misc = importlib.import_module('basicsr.utils.misc')
+        utils.scandir = misc.scandir
+        utils.img2tensor = None
+        placeholder = 'cv2' not in sys.modules
+        if placeholder:
+            sys.modules['cv2'] = types.ModuleType('cv2')
+        try:
+            data_util = importlib.import_module('basicsr.data.data_util')
+        finally:
+            if placeholder:
+                del sys.modules['cv2']
+    except Exception:  # pragma: no cover - optional
+        data_util = None
+
     options_mod = None
     try:  # options.parse / dict2str: needs `set_random_seed` by name only
         utils.set_random_seed = lambda seed: None
@@ -129,6 +145,6 @@ def load_reference():
         MSELoss=loss_mod.MSELoss, CharbonnierLoss=loss_mod.CharbonnierLoss,
         lr_scheduler=lr_sched, SRModel=sr_model.SRModel, SRGANModel=srgan_model.SRGANModel,
         ESRGANModel=esrgan_model.ESRGANModel, data_sampler=sampler, build_network=build_network, transforms=transforms,
-        calculate_psnr=getattr(psnr_mod, 'calculate_psnr', None), options=options_mod)
+        calculate_psnr=getattr(psnr_mod, 'calculate_psnr', None), options=options_mod, data_util=data_util)
     b._sr_ns = ns
     return ns
