@@ -321,16 +321,18 @@ def main():
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(k0['kernel'])
+            upath = os.path.join(ROOT, 'profiles', 'r01_mfma_util.json')  # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, own --pmc passes
+            mfma_pmc = (json.load(open(upath)).get(k0['kernel']) or {}).get('mfma_util') if os.path.exists(upath) else None
             peak = PEAK_F32_TFLOPS if args.dtype == 'fp32' else PEAK_BF16_TFLOPS
             mfma_frac, hbm_frac = k0['tflops'] / peak, k0['hbm_frac']
             if mfma_frac >= hbm_frac:  # the binding roof is the one the kernel sits closer to
                 line['roofline'] = {'bound': 'mfma', 'achieved': k0['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                                     'frac': round(mfma_frac, 4), 'traffic': traffic, 'kernel': k0['kernel'],
-                                    'avg_launch_ms': k0['avg_ms'], 'hbm_frac_algorithmic': k0['hbm_frac']}
+                                    'avg_launch_ms': k0['avg_ms'], 'hbm_frac_algorithmic': k0['hbm_frac'], 'mfma_util_pmc': mfma_pmc}
             else:  # bf16 per-layer convs: 192-272 FLOP/B against a ridge of ~310 -> memory side binds
                 line['roofline'] = {'bound': 'hbm', 'achieved': k0['alg_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(hbm_frac, 4), 'traffic': traffic, 'kernel': k0['kernel'],
-                                    'avg_launch_ms': k0['avg_ms'], 'mfma_frac': round(mfma_frac, 4)}
+                                    'avg_launch_ms': k0['avg_ms'], 'mfma_frac': round(mfma_frac, 4), 'mfma_util_pmc': mfma_pmc}
             line['kernels'] = ks
             if not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline()
