@@ -1,0 +1,30 @@
+"""Soak: 300 ESRGAN steps (bf16 generator, U-Net discriminator, perceptual loss) with changing batch and patch sizes; allocated
+and reserved device memory must stay flat."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from image_restoration_amd.models import build_model
+from image_restoration_amd.utils.synth import smooth_pairs
+adam = dict(type='Adam', lr=1e-4, weight_decay=0, betas=[0.9, 0.99])
+opt = dict(name='soak', model_type='ESRGANModel', scale=4, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
+           network_g=dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=4, num_grow_ch=32, compute_dtype='bf16'),
+           network_d=dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True, compute_dtype='bf16'),
+           path=dict(pretrain_network_g=None, strict_load_g=True, pretrain_network_d=None),
+           train=dict(ema_decay=0.999, optim_g=dict(adam), optim_d=dict(adam), scheduler=dict(type='MultiStepLR', milestones=[10 ** 6], gamma=0.5),
+                      total_iter=300, warmup_iter=-1, pixel_opt=dict(type='L1Loss', loss_weight=1e-2, reduction='mean'),
+                      perceptual_opt=dict(type='PerceptualLoss', layer_weights={'conv5_4': 1.0}, vgg_type='vgg19', perceptual_weight=1.0, style_weight=0, criterion='l1', compute_dtype='bf16'),
+                      gan_opt=dict(type='GANLoss', gan_type='vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight=5e-3), net_d_iters=1, net_d_init_iters=0))
+model = build_model(opt)
+mem = []
+for it in range(1, 301):
+    n = 4 if it % 7 else 3          # batch size changes now and then (workspaces are re-sized)
+    lq, gt = smooth_pairs(it, n, 128 if it % 11 else 96)
+    model.update_learning_rate(it, warmup_iter=-1)
+    model.feed_data({'lq': lq, 'gt': gt})
+    model.optimize_parameters(it)
+    if it % 50 == 0:
+        torch.cuda.synchronize()
+        mem.append((it, torch.cuda.memory_allocated() >> 20, torch.cuda.memory_reserved() >> 20, {k: round(float(v), 4) for k, v in model.get_current_log().items()}))
+        print(mem[-1], flush=True)
+assert mem[-1][2] <= mem[1][2] * 1.1 + 64, 'reserved memory keeps growing'
+print('soak ok')
