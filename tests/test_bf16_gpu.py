@@ -326,3 +326,39 @@ def test_rdb_wgrad_bf16_single_launch_matches_per_conv_launches(nf, gc, n, h, w)
         tol = 2e-5 * float(dw.abs().max()) + 1e-5
         assert float((gw - dw).abs().max()) <= tol, (k, float((gw - dw).abs().max()), tol)
         assert float((gb - db).abs().max()) <= 2e-5 * float(db.abs().max()) + 1e-4, k
+
+
+@pytest.mark.parametrize('cfg,shape', [
+    (dict(num_in_ch=1, num_out_ch=5, scale=2, num_feat=32, num_block=2, num_grow_ch=16), (2, 1, 36, 32)),
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32), (2, 3, 24, 40)),
+    (dict(num_in_ch=4, num_out_ch=1, scale=1, num_feat=48, num_block=1, num_grow_ch=16), (1, 4, 32, 48)),
+])
+def test_bf16_gradients_equal_a_float64_model_of_bf16_storage(cfg, shape):
+    """Against the fp32 reference the bf16 gradients of these small nets differ by 5-25 % per parameter.  Is that the kernels
+    or bf16 itself?  oracle/bf16_sim.py runs the network in float64 with a bf16 round trip at every point where the HIP path
+    stores a tensor (input, packed weights, conv outputs, activation gradients).  Against THAT model the HIP bf16 output agrees
+    to 1e-3 relative L2 (measured 0.6e-4 .. 2.2e-4; 2e-3 .. 7e-3 against fp32) and every gradient to 3e-2 (measured worst
+    1.0e-2 .. 1.6e-2, median 0.6e-2 .. 0.9e-2; what remains are the exact places where sums are rounded, fp32 accumulation and
+    LeakyReLU signs of values within rounding of zero) — an order of magnitude tighter than the distance of either from the
+    fp32 reference, i.e. the error of the bf16 path is the error of bf16 storage, not of the kernels."""
+    import image_restoration_amd as ira
+    from image_restoration_amd.utils import synth
+    from oracle.bf16_sim import rrdbnet_forward_bf16_storage
+    sd_np = synth.rrdbnet_state_dict(5, **cfg)
+    x_np = synth.uniform_input(6, shape)
+    sd = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd_np.items()}
+    xr = torch.from_numpy(x_np).double().requires_grad_(True)
+    yr = rrdbnet_forward_bf16_storage(xr, sd, cfg['scale'], cfg['num_block'])
+    Rw = torch.from_numpy(synth.signed_input(9, tuple(yr.shape)))
+    (yr * Rw.double()).sum().backward()
+    net = ira.build_network(dict(type='RRDBNet', compute_dtype='bf16', **cfg)).cuda()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    y = net(x)
+    (y * Rw.cuda()).sum().backward()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(y.detach(), yr.detach()) < 1e-3
+    errs = sorted([rel(x.grad, xr.grad)] + [rel(p.grad, sd[k].grad) for k, p in net.named_parameters()])
+    assert errs[-1] < 3e-2 and errs[len(errs) // 2] < 1.5e-2, (errs[-1], errs[len(errs) // 2])
