@@ -1,13 +1,14 @@
 """Randomised whole-network check: RRDBNet forward + every gradient on the HIP path (fp32 and bf16) against PyTorch-CPU autograd
 through the oracle (test infrastructure: oracle/rrdbnet_ref.py) for random (num_feat, num_grow_ch, num_block, scale, channels, shape).
-fp32: output 1e-4, gradients relative-L2 2e-3 (LeakyReLU sign flips, see tests/test_backward_gpu.py); bf16: output relative-L2 3e-2,
-gradients relative-L2 0.15.  Exit code 1 on any mismatch."""
+fp32: output 1e-4, gradients relative-L2 2e-3 (LeakyReLU sign flips, see tests/test_backward_gpu.py); bf16 against the float64
+model of bf16 storage (oracle/bf16_sim.py): output relative-L2 1e-3, gradients 5e-2.  Exit code 1 on any mismatch."""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import image_restoration_amd as ira
 from image_restoration_amd.utils import synth
 from oracle import rrdbnet_ref as R
+from oracle.bf16_sim import rrdbnet_forward_bf16_storage
 
 random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -32,16 +33,24 @@ for it in range(N):
     yr = R.rrdbnet_forward(xr, sd, scale, cfg['num_block'])
     Rw = torch.from_numpy(synth.signed_input(9, tuple(yr.shape)))
     (yr * Rw).sum().backward()
+    sd16 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd_np.items()}
+    x16 = torch.from_numpy(x_np).double().requires_grad_(True)
+    y16 = rrdbnet_forward_bf16_storage(x16, sd16, scale, cfg['num_block'])
+    (y16 * Rw.double()).sum().backward()
     line = f'{it:2d} {cfg} x={n}x{h}x{w}:'
-    for dtype, tol_y, tol_g in (('fp32', 1e-4, 2e-3), ('bf16', None, 0.15)):
+    for dtype, tol_y, tol_g in (('fp32', 1e-4, 2e-3), ('bf16', None, 5e-2)):
         net = ira.build_network(dict(type='RRDBNet', compute_dtype=dtype, **cfg)).to(dev)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
         x = torch.from_numpy(x_np).to(dev).requires_grad_(True)
         y = net(x)
         (y * Rw.to(dev)).sum().backward()
-        ey = float((y.detach().cpu() - yr.detach()).abs().max()) if tol_y else rel(y.detach().cpu(), yr.detach())
-        eg = max([rel(x.grad.cpu(), xr.grad)] + [rel(p.grad.cpu(), sd[k].grad) for k, p in net.named_parameters()])
-        ok = ey < (tol_y or 3e-2) and eg < tol_g
+        if dtype == 'fp32':
+            ey = float((y.detach().cpu() - yr.detach()).abs().max())
+            eg = max([rel(x.grad.cpu(), xr.grad)] + [rel(p.grad.cpu(), sd[k].grad) for k, p in net.named_parameters()])
+        else:
+            ey = rel(y.detach().cpu(), y16.detach())
+            eg = max([rel(x.grad.cpu(), x16.grad)] + [rel(p.grad.cpu(), sd16[k].grad) for k, p in net.named_parameters()])
+        ok = ey < (tol_y or 1e-3) and eg < tol_g
         bad += not ok
         line += f'  {dtype} out {ey:.1e} grad {eg:.1e} {"ok" if ok else "MISMATCH"}'
     print(line, flush=True)
