@@ -49,3 +49,32 @@ def rrdbnet_forward_bf16_storage(x, sd, scale=4, num_block=23):
     feat = r(lr(cv(F.interpolate(feat, scale_factor=2, mode='nearest'), 'conv_up1')))
     feat = r(lr(cv(F.interpolate(feat, scale_factor=2, mode='nearest'), 'conv_up2')))
     return cv(r(lr(cv(feat, 'conv_hr'))), 'conv_last')
+
+
+def unet_forward_bf16_storage(x, w, skip_connection=True):
+    """UNetDiscriminatorSN (oracle/unet_discriminator_ref.py) in float64 with the bf16 round trips of the HIP bf16 path.
+    `w`: effective (already spectrally normalised) weights 'conv0.weight', 'conv0.bias', 'conv1.weight' ... 'conv9.bias'."""
+    r = _RoundTrip.apply
+
+    def cv(t, name, stride=1):
+        wt = w[name + '.weight']
+        wq = wt.detach().to(torch.bfloat16).to(torch.float64) + (wt - wt.detach())
+        return F.conv2d(t, wq, w.get(name + '.bias'), stride=stride, padding=1)
+
+    def lr(t):
+        return F.leaky_relu(t, 0.2)
+
+    def up(t):
+        return r(F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False))
+    x0 = r(lr(cv(r(x), 'conv0')))
+    x1 = r(lr(cv(x0, 'conv1', 2)))
+    x2 = r(lr(cv(x1, 'conv2', 2)))
+    x3 = r(lr(cv(x2, 'conv3', 2)))
+    x4 = r(lr(cv(up(x3), 'conv4')))
+    x5 = r(lr(cv(up(r(x4 + x2) if skip_connection else x4), 'conv5')))
+    x6 = r(lr(cv(up(r(x5 + x1) if skip_connection else x5), 'conv6')))
+    if skip_connection:
+        x6 = r(x6 + x0)
+    out = r(lr(cv(x6, 'conv7')))
+    out = r(lr(cv(out, 'conv8')))
+    return cv(out, 'conv9')

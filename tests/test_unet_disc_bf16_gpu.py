@@ -265,3 +265,40 @@ def test_c3_training_config_runs_all_bf16(cuda):
         assert all(np.isfinite(v) for v in log.values()), log
     assert not torch.equal(model.net_g.conv_last.weight, w0) and not torch.equal(model.net_d.conv9.weight, d0)
     assert not torch.equal(model.net_g_ema.conv_last.weight, w0)
+
+
+def test_unet_bf16_equals_a_float64_model_of_bf16_storage(cuda):
+    """The bf16 U-Net (fused fork / add-bilinear / epilogue-mask passes) against oracle/bf16_sim.py — float64 arithmetic with a
+    bf16 round trip wherever the HIP path stores a tensor — on the effective (spectrally normalised) weights, eval mode:
+    logits to 5e-3 relative L2, input gradient and the gradients of the plain parameters (conv0, conv9) to 3e-2; against the
+    fp32 path the same quantities differ by 2-8 % (test above)."""
+    from oracle.bf16_sim import unet_forward_bf16_storage
+    torch.manual_seed(11)
+    net = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=16, skip_connection=True, compute_dtype='bf16')).to(cuda)
+    with torch.no_grad():
+        for _ in range(12):  # let the power iterations settle so that the normalised weights (and logits) are O(1)
+            net(torch.rand(1, 3, 16, 16, device=cuda))
+    net.eval()
+    w = {}
+    for i in range(10):
+        conv = getattr(net, f'conv{i}')
+        wt = conv.weight if i in (0, 9) else conv.weight()  # SN layers: the normalised weight the forward uses (eval: no update)
+        w[f'conv{i}.weight'] = wt.detach().cpu().double().requires_grad_(True)
+        if i in (0, 9):
+            w[f'conv{i}.bias'] = conv.bias.detach().cpu().double().requires_grad_(True)
+    x = torch.rand(2, 3, 48, 64)
+    xr = x.double().requires_grad_(True)
+    yr = unet_forward_bf16_storage(xr, w)
+    R = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1))
+    (yr * R.double()).sum().backward()
+    xc = x.to(cuda).requires_grad_(True)
+    y = net(xc)
+    (y * R.to(cuda)).sum().backward()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(y.detach(), yr.detach()) < 5e-3
+    assert rel(xc.grad, xr.grad) < 3e-2
+    for name, p in (('conv0.weight', net.conv0.weight), ('conv0.bias', net.conv0.bias), ('conv9.weight', net.conv9.weight),
+                    ('conv9.bias', net.conv9.bias)):
+        assert rel(p.grad, w[name].grad) < 3e-2, name
