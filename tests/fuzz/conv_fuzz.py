@@ -2,7 +2,7 @@
 sr_conv3x3_f32 against torch's CPU convolution, sr_conv3x3_bf16 against sr_conv3x3_f32 (bf16-rounded operands), with
 upsampling, residuals, the LeakyReLU-backward mask and concat-style channel counts.  Exit code 1 on any mismatch."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from image_restoration_amd import hip_ops as ops

@@ -2,7 +2,7 @@
 widths / sizes / skip settings / train-eval mode (oracle/unet_discriminator_ref.py), VGGStyleDiscriminator128 / 256 over random widths
 and batch sizes (oracle/discriminator_ref.py): logits, input gradient and every parameter gradient.  Exit code 1 on a mismatch."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import image_restoration_amd as ira

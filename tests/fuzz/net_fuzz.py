@@ -3,7 +3,7 @@ through the oracle (test infrastructure: oracle/rrdbnet_ref.py) for random (num_
 fp32: output 1e-4, gradients relative-L2 2e-3 (LeakyReLU sign flips, see tests/test_backward_gpu.py); bf16 against the float64
 model of bf16 storage (oracle/bf16_sim.py): output relative-L2 1e-3, gradients 5e-2.  Exit code 1 on any mismatch."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import image_restoration_amd as ira
 from image_restoration_amd.utils import synth

@@ -1,7 +1,7 @@
 """Robustness sweep: generator and discriminators, forward + backward, over batch sizes and resolutions the tests do not pin,
 in fp32 and bf16.  Prints every (network, dtype, shape) that raises or produces non-finite values; exit code 1 if any."""
 import sys, os, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import image_restoration_amd as ira
 

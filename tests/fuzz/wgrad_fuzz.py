@@ -1,7 +1,7 @@
 """Randomised differential check of the weight-gradient entry points: sr_conv3x3_wgrad_f32 against torch's CPU autograd
 (float64), sr_conv3x3_wgrad_bf16 against the same reference on bf16-rounded operands.  Exit code 1 on any mismatch."""
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from image_restoration_amd import hip_ops as ops
