@@ -236,3 +236,27 @@ def test_test_entry_point_saves_images_and_metrics(cuda, tmp_path):
         want = tensor2img([net(lq.to(cuda)).cpu()], rgb2bgr=False)
     assert np.array_equal(np.asarray(Image.open(vis / 'lq_only' / 'p1_x4.png')), want)
     assert not hasattr(model, 'optimizer_g')  # test mode builds no training state
+
+
+def test_inference_script_sharded_over_two_processes(cuda, tmp_path):
+    """python -m torch.distributed.run ... inference --launcher pytorch --tile: two ranks (gloo rendezvous, sharing this GPU) split
+    the tiles of a frame; rank 0's assembled PNG is bit-identical to the single-process tiled result."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from image_restoration_amd import inference
+    rng = np.random.default_rng(3)
+    Image.fromarray(rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)).save(tmp_path / 'a.png')
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=32, num_block=1, num_grow_ch=32)
+    torch.save({'params': {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(1, **cfg).items()}}, tmp_path / 'g.pth')
+    common = ['--input', str(tmp_path / 'a.png'), '--model_path', str(tmp_path / 'g.pth'), '--num_feat', '32', '--num_block', '1',
+              '--tile', '32', '--tile_pad', '8']
+    inference.main(common + ['--output', str(tmp_path / 'single.png')])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(29600 + os.getpid() % 300), '-m', 'image_restoration_amd.inference', '--launcher', 'pytorch',
+                        '--dist_backend', 'gloo', '--output', str(tmp_path / 'dist.png')] + common,
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / 'single.png')), np.asarray(Image.open(tmp_path / 'dist.png')))
