@@ -134,3 +134,27 @@ def test_batch_independence_and_determinism(cuda):
     assert torch.equal(y, y2)
     assert torch.equal(y[5:6], y5)
     assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_forward_is_graph_capturable(cuda, dtype):
+    """include/sr_hip.h promises that the whole-network forward neither allocates nor synchronises: capture it in a HIP graph
+    (torch.cuda.graph; the bf16 forward forks / joins its image-group streams inside the capture) and replay on new input."""
+    net = ira.build_network(dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32,
+                                 compute_dtype=dtype)).to(cuda).eval()
+    x = torch.rand(16, 3, 64, 64, device=cuda)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                net(x)  # packs the weights, sizes the workspace
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y = net(x)
+        x.copy_(torch.rand_like(x))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = y.clone()
+        assert torch.equal(got, net(x))
