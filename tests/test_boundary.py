@@ -94,3 +94,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.sr_conv3x3_cin_pad(45, 20, 12) < 0
     bad = _lib.RRDBNetCfg(3, 3, 3, 64, 23, 32)
     assert lib.sr_rrdbnet_num_params(ctypes.byref(bad)) < 0
+
+
+def test_argument_errors_are_codes_with_messages_not_crashes():
+    """Bad arguments come back as negative status codes with a message in sr_last_error() before anything is launched (so
+    this runs without a GPU): null pointers, misaligned channel counts, bad configurations, out-of-range knobs."""
+    lib = _lib.load()
+
+    def failed(rc, word):
+        msg = lib.sr_last_error().decode()
+        return rc < 0 and word in msg
+    assert failed(lib.sr_conv3x3_f32(None, None), 'null')
+    d = _lib.ConvDesc()
+    d.in_, d.wpacked, d.out = 256, 256, 256  # non-null, aligned placeholders: the shape checks come first
+    d.cin_pad, d.cout, d.n, d.in_h, d.in_w = 12, 32, 1, 8, 8
+    assert failed(lib.sr_conv3x3_f32(ctypes.byref(d), None), 'multiple of 8')
+    d.cin_pad = 24
+    assert failed(lib.sr_conv3x3_bf16(ctypes.byref(d), None), 'multiple of 16')
+    d.cin_pad, d.s2_channels = 64, 32
+    assert failed(lib.sr_conv3x3_bf16(ctypes.byref(d), None), 's2_channels')
+    assert failed(lib.sr_cb16_add_bf16(256, 256, 256, 12, None), 'multiple of 8')
+    assert failed(lib.sr_set_forward_groups(9), '1..4')
+    assert lib.sr_set_forward_groups(0) == 0
+    bad = _lib.RRDBNetCfg(3, 3, 3, 64, 23, 32)
+    assert failed(lib.sr_rrdbnet_forward_f32(ctypes.byref(bad), 256, 256, 256, 1, 8, 8, 256, 1 << 20, None), 'config')
+    good = _lib.RRDBNetCfg(3, 3, 2, 16, 1, 8)
+    assert failed(lib.sr_rrdbnet_forward_f32(ctypes.byref(good), 256, 256, 256, 1, 9, 8, 256, 1 << 30, None), 'divisible')
+    assert failed(lib.sr_gan_point_loss_fwd_f32(256, 16, 9, 0.0, 1.0, 256, 256, 1 << 20, None), 'bad argument')
