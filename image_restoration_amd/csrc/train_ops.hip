@@ -425,13 +425,16 @@ __global__ void bilinear2x_bwd_kernel(const float* __restrict__ g, long long g_n
 
 // ------------------------------------------------------------------ spectral norm (torch.nn.utils.spectral_norm)
 // W viewed as [rows][cols] row-major.  t = W^T u : one thread per column.
+// t = W^T u in row chunks: block (x, y) sums rows [y*chunk, (y+1)*chunk) for 256 columns into t[y][cols]; the single-block
+// normalisation that follows adds the chunks in fixed order (a column walk over all rows on cols/256 workgroups took 70 us)
 __global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int rows,
-                               int cols) {
+                               int cols, int chunk) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
+  const int r0 = blockIdx.y * chunk, r1 = min(r0 + chunk, rows);
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += W[(long long)r * cols + c] * u[r];
-  t[c] = s;
+  for (int r = r0; r < r1; ++r) s += W[(long long)r * cols + c] * u[r];
+  t[(long long)blockIdx.y * cols + c] = s;
 }
 // s = W v : one block per row
 __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
@@ -444,9 +447,17 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W
   if (threadIdx.x == 0) s[r] = a;
 }
 // single block: out = x / max(||x||, eps); if sigma: sigma[0] = out . x
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
-                                                           float eps, float* sigma) {
+__global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ x, float* __restrict__ out, int n,
+                                                           float eps, float* sigma, int parts) {
   __shared__ float sh[4];
+  if (parts > 1) {  // x holds `parts` partial vectors behind one another: fold them into the first
+    for (int i = threadIdx.x; i < n; i += 256) {
+      float s = 0.f;
+      for (int y = 0; y < parts; ++y) s += x[(long long)y * n + i];
+      x[i] = s;
+    }
+    __syncthreads();
+  }
   float a = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) a += x[i] * x[i];
   a = block_sum(a, sh);
@@ -905,14 +916,15 @@ extern "C" int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v,
                                         float* w_sn, float* sigma, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(w_orig && u && v && w_sn && sigma && ws && rows > 0 && cols > 0, "sr_spectral_norm_fwd_f32: bad argument");
-  SR_CHECK_ARG(ws_bytes >= (size_t)(rows + cols) * sizeof(float), "sr_spectral_norm_fwd_f32: workspace too small");
-  float* t = (float*)ws;      // [cols]
-  float* s = t + cols;        // [rows]
+  SR_CHECK_ARG(ws_bytes >= ((size_t)rows + (size_t)16 * cols) * sizeof(float), "sr_spectral_norm_fwd_f32: workspace too small");
+  float* t = (float*)ws;           // [<= 16 row chunks][cols]
+  float* s = t + (size_t)16 * cols;  // [rows]
   if (update) {  // one power iteration: v = normalize(W^T u); u = normalize(W v)  (in place, like the reference module)
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(nblk(cols)), dim3(256), 0, stream, w_orig, u, t, rows, cols);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, t, v, cols, eps, (float*)nullptr);
+    const int parts = rows >= 512 ? 16 : rows >= 64 ? 8 : 1, chunk = (rows + parts - 1) / parts;
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(nblk(cols), parts), dim3(256), 0, stream, w_orig, u, t, rows, cols, chunk);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, t, v, cols, eps, (float*)nullptr, parts);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, s, cols);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, s, u, rows, eps, sigma);  // sigma = u.(Wv)
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, stream, s, u, rows, eps, sigma, 1);  // sigma = u.(Wv)
   } else {
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, stream, w_orig, v, s, cols);
     hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, stream, u, s, rows, sigma);

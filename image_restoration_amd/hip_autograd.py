@@ -405,7 +405,7 @@ class SpectralNormFn(torch.autograd.Function):
         dev = w.device
         w_sn = torch.empty_like(w)
         sigma = torch.empty((), dtype=torch.float32, device=dev)
-        wsb = max((rows + cols) * 4, lib.sr_reduce_workspace_bytes(8) + 64)
+        wsb = max((rows + 16 * cols) * 4, lib.sr_reduce_workspace_bytes(8) + 64)
         ws = scratch(dev, wsb)
         with torch.cuda.device(dev):
             _lib.check(lib.sr_spectral_norm_fwd_f32(w.data_ptr(), u.data_ptr(), v.data_ptr(), rows, cols, int(update), eps,

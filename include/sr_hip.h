@@ -209,7 +209,7 @@ int sr_bilinear2x_bwd_f32(const float* g, int64_t g_img_stride, float* gsrc, int
 
 /* torch.nn.utils.spectral_norm (dim 0, one power iteration, eps 1e-12) on a weight viewed as [rows][cols]:
  *   update=1 (train): v = normalize(W^T u), u = normalize(W v) in place; sigma = u.(W v); w_sn = W / sigma.
- *   update=0 (eval) : stored u, v.     ws >= (rows+cols)*4 bytes.
+ *   update=0 (eval) : stored u, v.     ws >= (rows + 16*cols)*4 bytes.
  * backward (u, v constants): g_worig = (g_wsn - sum(g_wsn*w_sn) * u v^T) / sigma. */
 int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v, int rows, int cols, int update, float eps,
                              float* w_sn, float* sigma, void* ws, size_t ws_bytes, void* stream);
