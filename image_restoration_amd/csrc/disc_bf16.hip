@@ -231,76 +231,44 @@ __global__ void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long lon
     }
   }
 }
-// gsrc[y][x] = sum over the (at most 4x4) outputs whose taps touch (y, x): a gather, deterministic.  A thread makes a 2x2
-// block of source pixels (8 channels) from the 6x6 window of output gradients around it: 36 loads per 4 results instead of
-// 64 (the pass is bound by L2 reads of the large gradient tensor); weights come from the forward's tap rule, so borders
-// (clamped taps) need no special case.
+// gsrc[y][x] = sum over the (at most 4x4) outputs whose taps touch (y, x): a gather, deterministic
 __global__ void bilinear2x_bwd16_kernel(const __bf16* __restrict__ g, long long g_ns, __bf16* __restrict__ gsrc, long long gsrc_ns,
                                         int cblocks, int h, int w, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int half = (int)(i & 1);
   long long r = i >> 1;
-  const int bw = (w + 1) / 2, bh = (h + 1) / 2;
-  const int bx = (int)(r % bw);
-  r /= bw;
-  const int by = (int)(r % bh);
-  r /= bh;
+  const int x = (int)(r % w);
+  r /= w;
+  const int y = (int)(r % h);
+  r /= h;
   const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
   const int W2 = 2 * w, H2 = 2 * h;
   const __bf16* b = g + n * g_ns + (long long)cb * H2 * W2 * 16 + half * 8;
-  // weight of output row (4 by - 1 + k) on source row (2 by + s), k = 0..5, s = 0..1; same for columns
-  float wy[2][6], wx[2][6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int oy = 4 * by - 1 + k, ox = 4 * bx - 1 + k;
-    int t0, t1;
-    float u0, u1;
-    const bool vy = oy >= 0 && oy < H2, vx = ox >= 0 && ox < W2;
-    bil_taps16(vy ? oy : 0, h, t0, t1, u0, u1);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) wy[s2][k] = vy ? (t0 == 2 * by + s2 ? u0 : 0.f) + (t1 == 2 * by + s2 ? u1 : 0.f) : 0.f;
-    bil_taps16(vx ? ox : 0, w, t0, t1, u0, u1);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) wx[s2][k] = vx ? (t0 == 2 * bx + s2 ? u0 : 0.f) + (t1 == 2 * bx + s2 ? u1 : 0.f) : 0.f;
-  }
-  float acc[2][2][8];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[a][c][e] = 0.f;
-#pragma unroll
-  for (int ky = 0; ky < 6; ++ky) {
-    const int oy = 4 * by - 1 + ky;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int oy = 2 * y - 1; oy <= 2 * y + 2; ++oy) {
     if (oy < 0 || oy >= H2) continue;
-#pragma unroll
-    for (int kx = 0; kx < 6; ++kx) {
-      const int ox = 4 * bx - 1 + kx;
+    int y0, y1;
+    float wy0, wy1;
+    bil_taps16(oy, h, y0, y1, wy0, wy1);
+    const float wy = (y0 == y ? wy0 : 0.f) + (y1 == y ? wy1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = 2 * x - 1; ox <= 2 * x + 2; ++ox) {
       if (ox < 0 || ox >= W2) continue;
+      int x0, x1;
+      float wx0, wx1;
+      bil_taps16(ox, w, x0, x1, wx0, wx1);
+      const float wgt = wy * ((x0 == x ? wx0 : 0.f) + (x1 == x ? wx1 : 0.f));
+      if (wgt == 0.f) continue;
       const bf16x8_t v = *(const bf16x8_t*)(b + ((long long)oy * W2 + ox) * 16);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float wgt = wy[a][ky] * wx[c][kx];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[a][c][e] += wgt * (float)v[e];
-        }
+      for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
     }
   }
+  bf16x8_t o;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int y = 2 * by + a, x = 2 * bx + c;
-      if (y >= h || x >= w) continue;
-      bf16x8_t o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[a][c][e];
-      *(bf16x8_t*)(gsrc + n * gsrc_ns + (((long long)cb * h + y) * w + x) * 16 + half * 8) = o;
-    }
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+  *(bf16x8_t*)(gsrc + n * gsrc_ns + (((long long)cb * h + y) * w + x) * 16 + half * 8) = o;
 }
 
 // W [cout][cin][4][4] <-> W' [cout][4 cin][3][3] (see the header comment); thread per (co, c, ky, kx)
@@ -406,7 +374,7 @@ extern "C" int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_ns, void* gsrc, i
                                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(g && gsrc && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_bwd_bf16: bad argument");
-  const long long total = (long long)n * cblocks * ((h + 1) / 2) * ((w + 1) / 2) * 2;  // one thread per 2x2 source block half
+  const long long total = (long long)n * cblocks * h * w * 2;
   hipLaunchKernelGGL(bilinear2x_bwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g, (long long)g_ns,
                      (__bf16*)gsrc, (long long)gsrc_ns, cblocks, h, w, total);
   SR_CHECK_LAUNCH("bilinear2x_bwd16");

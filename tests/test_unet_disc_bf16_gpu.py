@@ -58,8 +58,8 @@ def test_conv4x4s2_as_unshuffled_3x3(cuda, cin, cout, n, h, w):
 
 @pytest.mark.parametrize('shape', [(2, 32, 6, 10), (1, 16, 5, 7), (3, 16, 1, 1), (1, 48, 2, 9), (2, 16, 33, 18)])
 def test_bilinear2x_bf16(cuda, shape):
-    """Forward (2x2 output block per source pixel) and backward (2x2 source block from a 6x6 gradient window) of the x2 bilinear
-    resampling against F.interpolate in float64 on the bf16-rounded tensors, odd and degenerate sizes included."""
+    """Forward (2x2 output block per source pixel) and backward (gather over the outputs that touch a source pixel) of the x2
+    bilinear resampling against F.interpolate in float64 on the bf16-rounded tensors, odd and degenerate sizes included."""
     n, c, h, w = shape
     x = torch.randn(*shape)
     xr = _bf(x).requires_grad_(True)
