@@ -40,6 +40,27 @@ __global__ void unshuffle2_kernel(const __bf16* __restrict__ src, long long src_
     *(bf16x8_t*)(dst + small) = *(const bf16x8_t*)(src + big);
 }
 
+// Forward pixel unshuffle with whole-line reads: a thread owns one pixel PAIR (2x, 2x+1) of one big row (8 channels) and
+// stores it to the two column-parity planes, so a wave reads contiguous memory instead of every other 32-byte pixel.
+__global__ void unshuffle2_pairs_kernel(const __bf16* __restrict__ src, long long src_ns, __bf16* __restrict__ dst, long long dst_ns,
+                                        int cblocks, int h, int w, long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int x = (int)(r % w);
+  r /= w;
+  const int Y = (int)(r % (2 * h));
+  r /= 2 * h;
+  const int cb = (int)(r % cblocks), n = (int)(r / cblocks);
+  const int y = Y >> 1, ry = Y & 1;
+  const __bf16* b = src + n * src_ns + (((long long)cb * 2 * h + Y) * (2 * w) + 2 * x) * 16 + half * 8;
+  const bf16x8_t p0 = *(const bf16x8_t*)b, p1 = *(const bf16x8_t*)(b + 16);
+  __bf16* o = dst + n * dst_ns + half * 8;
+  *(bf16x8_t*)(o + (((long long)((2 * ry + 0) * cblocks + cb) * h + y) * w + x) * 16) = p0;
+  *(bf16x8_t*)(o + (((long long)((2 * ry + 1) * cblocks + cb) * h + y) * w + x) * 16) = p1;
+}
+
 // out = bf16(a + b), 8 elements per thread (skip connection in one pass)
 __global__ void add16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ out, long long n8) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,6 +317,12 @@ extern "C" int sr_cb16_unshuffle2_bf16(const void* src, int64_t src_img_stride, 
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(src && dst && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_unshuffle2_bf16: bad argument");
   const long long total = (long long)n * 4 * cblocks * h * w * 2;
+  if (!inverse) {
+    hipLaunchKernelGGL(unshuffle2_pairs_kernel, dim3(nblk(total / 2)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_img_stride,
+                       (__bf16*)dst, (long long)dst_img_stride, cblocks, h, w, total / 2);
+    SR_CHECK_LAUNCH("cb16_unshuffle2");
+    return SR_OK;
+  }
   hipLaunchKernelGGL(unshuffle2_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)src, (long long)src_img_stride,
                      (__bf16*)dst, (long long)dst_img_stride, cblocks, h, w, inverse, total);
   SR_CHECK_LAUNCH("cb16_unshuffle2");
