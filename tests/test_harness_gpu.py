@@ -260,3 +260,30 @@ def test_inference_script_sharded_over_two_processes(cuda, tmp_path):
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert np.array_equal(np.asarray(Image.open(tmp_path / 'single.png')), np.asarray(Image.open(tmp_path / 'dist.png')))
+
+
+def test_bench_line_contract(cuda):
+    """bench.py prints exactly one JSON line with the driver's fields, the roofline object of the dominant kernel and the CPU
+    baseline (checked on a short run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1'], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'images/sec' and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 16 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 0.05 * d['value']
+    rf = d['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert 0.5 < rf['frac'] < 1.0 and (rf['traffic'] is None or rf['traffic'] > 1e8)
+    cb = d['cpu_baseline']
+    assert cb['kind'] in ('port', 'reference') and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'images/sec' and cb['sample']
