@@ -46,7 +46,7 @@ def layer_names(vgg_type):
 class VGGFeatureExtractor(nn.Module):
 
     def __init__(self, layer_name_list, vgg_type='vgg19', use_input_norm=True, range_norm=False, requires_grad=False,
-                 remove_pooling=False, pooling_stride=2, weights_path=None, compute_dtype='fp32'):
+                 remove_pooling=False, pooling_stride=2, weights_path=None, compute_dtype='fp32', allow_random_init=False):
         super().__init__()
         if compute_dtype not in ('fp32', 'bf16'):
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
@@ -62,20 +62,30 @@ class VGGFeatureExtractor(nn.Module):
         self.names = self.names[:max_idx + 1]
         self.vgg_net = nn.Module()  # parameters live under vgg_net.convS_K like the reference's OrderedDict Sequential
         cin = 3
+        # Random features are an explicit opt-in (tests, benchmarks).  They come from a private generator with a fixed
+        # seed, so every rank of a job (seeded manual_seed + rank) builds the SAME extractor and optimises the same loss.
+        gen = torch.Generator().manual_seed(0x56474731)
         for name in self.names:
             if name.startswith('conv'):
                 cout = _WIDTHS[int(name[4]) - 1]
                 conv = Conv3x3Params(cin, cout, bias=True)
-                init.kaiming_normal_(conv.weight, mode='fan_out', nonlinearity='relu')  # torchvision's VGG._initialize_weights
+                init.kaiming_normal_(conv.weight, mode='fan_out', nonlinearity='relu', generator=gen)  # torchvision's VGG._initialize_weights
                 init.zeros_(conv.bias)
                 self.vgg_net.add_module(name, conv)
                 cin = cout
         path = weights_path or (VGG_PRETRAIN_PATH if os.path.exists(VGG_PRETRAIN_PATH) else None)
         if path:
             self.load_pretrained(torch.load(path, map_location='cpu', weights_only=True))
-        else:
+        elif allow_random_init:
             logging.getLogger('basicsr').warning(
-                'VGGFeatureExtractor: no pretrained weights (%s absent, torchvision not installed): random features', VGG_PRETRAIN_PATH)
+                'VGGFeatureExtractor: allow_random_init - no pretrained weights (%s absent), features are RANDOM', VGG_PRETRAIN_PATH)
+        else:
+            # the reference falls back to torchvision's download here; a perceptual loss on random features would train
+            # silently towards nothing, so refuse instead
+            raise FileNotFoundError(
+                f'VGGFeatureExtractor: no pretrained weights: {VGG_PRETRAIN_PATH} is absent and no weights_path was given '
+                '(torchvision is not available to fetch them).  Pass weights_path=<vgg19-dcbb9e9d.pth>, or '
+                'allow_random_init=True for tests / benchmarks.')
         for p in self.parameters():
             p.requires_grad = bool(requires_grad)
         # (x [+1]/2 - mean) / std as one per-channel affine

@@ -1,58 +1,70 @@
-"""Pairing of LQ / GT file paths (basicsr/data/data_util.py:108-231)."""
+"""Which LQ file belongs to which GT file (behaviour of basicsr/data/data_util.py:108-231, golden G-s).
+
+Three sources of pairs: two folders (LQ name = ``filename_tmpl.format(<GT stem>) + <GT extension>``), a meta-info file listing GT names,
+or two LMDB directories with equal key sets.  All return ``[{'<lq key>_path': ..., '<gt key>_path': ...}, ...]``."""
 import os
-import os.path as osp
 
 
 def scandir(folder):
-    """Relative paths of the files in ``folder`` (non-recursive, hidden files skipped), sorted."""
-    return sorted(e.name for e in os.scandir(folder) if e.is_file() and not e.name.startswith('.'))
+    """Names of the regular, non-hidden files directly inside ``folder``, sorted (the reference walks in os.scandir order, which
+    depends on the file system; sorting yields the same SET of pairs in a reproducible order)."""
+    with os.scandir(folder) as it:
+        return sorted(entry.name for entry in it if entry.is_file() and entry.name[:1] != '.')
+
+
+def _two(seq, what):
+    if len(seq) != 2:
+        raise AssertionError(f'The len of {what} should be 2 with [input_{what[:-1]}, gt_{what[:-1]}]. But got {len(seq)}')
+    return seq
+
+
+def _lq_name(gt_name, filename_tmpl):
+    stem, ext = os.path.splitext(os.path.basename(gt_name))
+    return filename_tmpl.format(stem) + ext
+
+
+def _pair(lq_key, gt_key, lq_value, gt_value):
+    return {lq_key + '_path': lq_value, gt_key + '_path': gt_value}
 
 
 def paired_paths_from_folder(folders, keys, filename_tmpl):
-    assert len(folders) == 2, f'The len of folders should be 2 with [input_folder, gt_folder]. But got {len(folders)}'
-    assert len(keys) == 2, f'The len of keys should be 2 with [input_key, gt_key]. But got {len(keys)}'
-    input_folder, gt_folder = folders
-    input_key, gt_key = keys
-    input_paths, gt_paths = scandir(input_folder), scandir(gt_folder)
-    assert len(input_paths) == len(gt_paths), (f'{input_key} and {gt_key} datasets have different number of images: '
-                                               f'{len(input_paths)}, {len(gt_paths)}.')
-    paths = []
-    known = set(input_paths)
-    for gt_path in gt_paths:
-        basename, ext = osp.splitext(osp.basename(gt_path))
-        input_name = f'{filename_tmpl.format(basename)}{ext}'
-        assert input_name in known, f'{input_name} is not in {input_key}_paths.'
-        paths.append({f'{input_key}_path': osp.join(input_folder, input_name), f'{gt_key}_path': osp.join(gt_folder, gt_path)})
-    return paths
+    lq_dir, gt_dir = _two(folders, 'folders')
+    lq_key, gt_key = _two(keys, 'keys')
+    lq_names, gt_names = scandir(lq_dir), scandir(gt_dir)
+    if len(lq_names) != len(gt_names):
+        raise AssertionError(f'{lq_key} and {gt_key} datasets have different number of images: {len(lq_names)}, {len(gt_names)}.')
+    present = frozenset(lq_names)
+    pairs = []
+    for gt_name in gt_names:
+        want = _lq_name(gt_name, filename_tmpl)
+        if want not in present:
+            raise AssertionError(f'{want} is not in {lq_key}_paths.')
+        pairs.append(_pair(lq_key, gt_key, os.path.join(lq_dir, want), os.path.join(gt_dir, gt_name)))
+    return pairs
 
 
 def paired_paths_from_meta_info_file(folders, keys, meta_info_file, filename_tmpl):
-    assert len(folders) == 2 and len(keys) == 2
-    input_folder, gt_folder = folders
-    input_key, gt_key = keys
-    with open(meta_info_file, 'r') as fin:
-        gt_names = [line.strip().split(' ')[0] for line in fin if line.strip()]
-    paths = []
-    for gt_name in gt_names:
-        basename, ext = osp.splitext(osp.basename(gt_name))
-        input_name = f'{filename_tmpl.format(basename)}{ext}'
-        paths.append({f'{input_key}_path': osp.join(input_folder, input_name), f'{gt_key}_path': osp.join(gt_folder, gt_name)})
-    return paths
+    """Each non-empty line of the meta-info file starts with a GT file name (anything after the first blank is ignored)."""
+    lq_dir, gt_dir = _two(folders, 'folders')
+    lq_key, gt_key = _two(keys, 'keys')
+    with open(meta_info_file) as f:
+        listed = [ln.split(' ')[0] for ln in (raw.strip() for raw in f) if ln]
+    return [_pair(lq_key, gt_key, os.path.join(lq_dir, _lq_name(n, filename_tmpl)), os.path.join(gt_dir, n)) for n in listed]
+
+
+def lmdb_keys(folder):
+    """Keys of an ``*.lmdb`` directory = the part before the first '.' of each ``meta_info.txt`` line (``name.png (h,w,c) level``)."""
+    with open(os.path.join(folder, 'meta_info.txt')) as f:
+        return [ln.split('.')[0] for ln in f]
 
 
 def paired_paths_from_lmdb(folders, keys):
-    """Both folders are ``*.lmdb`` directories with a ``meta_info.txt`` of ``name.png (h,w,c) compress`` lines; the keys of
-    the two databases must coincide (data_util.py:108-155)."""
-    assert len(folders) == 2 and len(keys) == 2
-    input_folder, gt_folder = folders
-    input_key, gt_key = keys
-    if not (input_folder.endswith('.lmdb') and gt_folder.endswith('.lmdb')):
-        raise ValueError(f'{input_key} folder and {gt_key} folder should both in lmdb formats. But received '
-                         f'{input_key}: {input_folder}; {gt_key}: {gt_folder}')
-    with open(osp.join(input_folder, 'meta_info.txt')) as fin:
-        input_keys = [line.split('.')[0] for line in fin]
-    with open(osp.join(gt_folder, 'meta_info.txt')) as fin:
-        gt_keys = [line.split('.')[0] for line in fin]
-    if set(input_keys) != set(gt_keys):
-        raise ValueError(f'Keys in {input_key}_folder and {gt_key}_folder are different.')
-    return [{f'{input_key}_path': k, f'{gt_key}_path': k} for k in sorted(set(input_keys))]
+    lq_dir, gt_dir = _two(folders, 'folders')
+    lq_key, gt_key = _two(keys, 'keys')
+    if not (lq_dir.endswith('.lmdb') and gt_dir.endswith('.lmdb')):
+        raise ValueError(f'{lq_key} folder and {gt_key} folder should both in lmdb formats. But received '
+                         f'{lq_key}: {lq_dir}; {gt_key}: {gt_dir}')
+    names = set(lmdb_keys(lq_dir))
+    if names != set(lmdb_keys(gt_dir)):
+        raise ValueError(f'Keys in {lq_key}_folder and {gt_key}_folder are different.')
+    return [_pair(lq_key, gt_key, n, n) for n in sorted(names)]

@@ -19,11 +19,13 @@ from .losses import L1Loss
 class PerceptualLoss(nn.Module):
 
     def __init__(self, layer_weights, vgg_type='vgg19', use_input_norm=True, range_norm=False, perceptual_weight=1.0,
-                 style_weight=0., criterion='l1', compute_dtype='fp32'):
+                 style_weight=0., criterion='l1', compute_dtype='fp32', weights_path=None,
+                 allow_random_init=False):
         super().__init__()
         self.perceptual_weight, self.style_weight, self.layer_weights = perceptual_weight, style_weight, dict(layer_weights)
         self.vgg = VGGFeatureExtractor(layer_name_list=list(self.layer_weights.keys()), vgg_type=vgg_type,
-                                       use_input_norm=use_input_norm, range_norm=range_norm, compute_dtype=compute_dtype)
+                                       use_input_norm=use_input_norm, range_norm=range_norm, compute_dtype=compute_dtype,
+                                       weights_path=weights_path, allow_random_init=allow_random_init)
         self.criterion_type = criterion
         if criterion == 'l1':
             self.criterion = L1Loss()

@@ -5,8 +5,6 @@ from .sr_model import SRModel  # noqa: F401
 from .srgan_model import SRGANModel  # noqa: F401
 from .esrgan_model import ESRGANModel  # noqa: F401
 
-__all__ = ['build_model']
-
 
 def build_model(opt):
     """The whole option dict -> model of class ``opt['model_type']``."""

@@ -1,198 +1,225 @@
-"""Training-side plumbing shared by the SR models.
+"""What every SR training model shares on the MI355X path.
 
-Counterpart of basicsr/models/base_model.py: device choice (:18), EMA (:50-57), optimiser factory (:78-83, Adam
-only), schedulers (:85-96), warm-up / learning-rate update (:144-168), network and training-state save/load
-(:170-326, same file formats and key names) and loss reduction to rank 0 (:328-353).
+Behavioural counterpart of basicsr/models/base_model.py — the contract is the *behaviour* a caller of the reference
+sees: device choice (:18), EMA (:50-57), Adam only (:78-83), the two restart schedulers (:85-96), linear warm-up
+(:144-168), the `net_<label>_<iter>.pth` / `<iter>.state` file formats and key names (:170-326) and the loss vector
+averaged onto rank 0 (:328-353).  The structure is this build's own: networks are held as ``NetPack``s (module +
+flat arenas + fused Adam + EMA shadow, models/netpack.py) instead of DDP-wrapped modules with per-tensor optimiser
+state.
 
-MI355X differences: networks are not wrapped in DistributedDataParallel — every network's parameters and
-gradients live in flat arenas (optim.FlatAdam) and data parallelism is one RCCL all-reduce of the gradient
-arena per optimiser step (reference semantics: DDP gradient mean, base_model.py:70-73).
+Data parallelism (reference: DistributedDataParallel, base_model.py:62-76).  There is no wrapper module.  Three
+things reproduce what DDP does for the reference:
+
+1. ``align_replicas()`` at the end of construction — parameters, buffers (BatchNorm statistics and counters,
+   spectral-norm u/v) and the EMA shadow of every pack become rank 0's.  This is DDP's constructor broadcast;
+   per-rank seeding stays ``manual_seed + rank`` as in the reference (options.py:148), so data order and
+   augmentation differ per rank while the networks do not.
+2. ``NetPack.update`` — one SUM all-reduce of the gradient arena per optimiser step, mean folded into Adam.
+3. ``refresh_buffers()`` at the start of every step when ``dist_params.broadcast_buffers`` is not false — DDP's
+   ``broadcast_buffers=True`` re-sends rank 0's buffers before each forward.  Train-mode BatchNorm never reads its
+   running statistics and only rank 0 saves / validates, so once per step (instead of once per forward) is
+   indistinguishable from outside; the deviation is stated here for completeness.
 """
 import logging
 import os
 import time
 from collections import OrderedDict
-from copy import deepcopy
 
 import torch
 
-from .. import optim
 from ..utils.dist_util import master_only
 from . import lr_scheduler
+from .netpack import NetPack
+
+_SCHEDULES = {'MultiStepLR': lr_scheduler.MultiStepRestartLR, 'MultiStepRestartLR': lr_scheduler.MultiStepRestartLR,
+              'CosineAnnealingRestartLR': lr_scheduler.CosineAnnealingRestartLR}
+
+
+def _bare(net):
+    """A module another framework wrapped (``.module``) is unwrapped; ours never are."""
+    inner = getattr(net, 'module', None)
+    return inner if isinstance(inner, torch.nn.Module) else net
+
+
+def _strip_module_prefix(state):
+    return OrderedDict((k[len('module.'):] if k.startswith('module.') else k, v) for k, v in state.items())
+
+
+def _write_with_retries(payload, path, what, attempts=3):
+    log = logging.getLogger('basicsr')
+    for left in range(attempts - 1, -1, -1):
+        try:
+            torch.save(payload, path)
+            return
+        except Exception as exc:  # noqa: BLE001 - a full disk or a flaky mount: wait and try again
+            log.warning(f'Save {what} error: {exc}, remaining retry times: {left}')
+            time.sleep(1)
+    raise IOError(f'Cannot save {path}.')
 
 
 class BaseModel:
 
     def __init__(self, opt):
         self.opt = opt
-        self.device = torch.device('cuda' if opt['num_gpu'] != 0 else 'cpu')
         self.is_train = opt['is_train']
-        self.schedulers = []
-        self.optimizers = []
+        self.device = torch.device('cpu' if opt['num_gpu'] == 0 else 'cuda')
+        self.distributed = bool(opt.get('dist'))
         self.logger = logging.getLogger('basicsr')
+        self.packs = OrderedDict()   # label ('g', 'd') -> NetPack
+        self.schedulers = []
+        self.log_dict = OrderedDict()
 
+    # ------------------------------------------------------------------ interface of the pipelines
     def feed_data(self, data):
-        pass
+        raise NotImplementedError
 
-    def optimize_parameters(self):
-        pass
+    def optimize_parameters(self, current_iter):
+        raise NotImplementedError
 
     def save(self, epoch, current_iter):
-        pass
+        raise NotImplementedError
 
     def get_current_log(self):
         return self.log_dict
 
     # ------------------------------------------------------------------ networks
+    def adopt(self, label, net, weights_key=None, shadow_key=None):
+        """Puts ``net`` on the device, loads ``path.pretrain_network_<label>`` when given and registers the pack.
+        ``path.strict_load_<label>`` and the ``params`` / ``params_ema`` file keys are the reference's."""
+        net = net.to(self.device)
+        self.report_network(net)
+        source = self.opt['path'].get(f'pretrain_network_{label}')
+        if source is not None:
+            self.load_network(net, source, self.opt['path'].get(f'strict_load_{label}', True),
+                              weights_key or 'params')
+        self.packs[label] = pack = NetPack(label, net)
+        return pack
+
     def model_to_device(self, net):
-        """Moves the network to the device.  No DDP/DataParallel wrapper: see the module docstring."""
+        """Kept for callers of the reference's name: device move only, never a wrapper."""
         return net.to(self.device)
 
     def get_bare_model(self, net):
-        return net.module if hasattr(net, 'module') and isinstance(net.module, torch.nn.Module) else net
+        return _bare(net)
+
+    @property
+    def optimizers(self):
+        return [p.adam for p in self.packs.values() if p.adam is not None]
 
     @master_only
-    def print_network(self, net):
-        net = self.get_bare_model(net)
-        n = sum(p.numel() for p in net.parameters())
-        self.logger.info(f'Network: {net.__class__.__name__}, with parameters: {n:,d}')
+    def report_network(self, net):
+        net = _bare(net)
+        count = sum(p.numel() for p in net.parameters())
+        self.logger.info(f'Network: {type(net).__name__}, with parameters: {count:,d}')
         self.logger.info(str(net))
 
+    print_network = report_network
+
+    def align_replicas(self):
+        """DDP's constructor-time ``_sync_module_states`` for every pack (module docstring, point 1)."""
+        if self.distributed and self.opt.get('world_size', 1) > 1:
+            for pack in self.packs.values():
+                pack.align_replicas()
+
+    def refresh_buffers(self):
+        if self.distributed and self.opt.get('world_size', 1) > 1 and \
+                (self.opt.get('dist_params') or {}).get('broadcast_buffers', True):
+            for pack in self.packs.values():
+                if any(True for _ in pack.net.buffers()):
+                    pack.align_replicas(buffers_only=True)
+
     def model_ema(self, decay=0.999):
-        """net_g_ema = decay*net_g_ema + (1-decay)*net_g over the parameter arenas (one launch)."""
-        if decay == 0 or not self._ema_flat.is_cuda:
-            with torch.no_grad():
-                if decay == 0:
-                    self._ema_flat.copy_(self.optimizer_g.flat_p)
-                else:
-                    raise RuntimeError('EMA update runs only on a HIP device')
-            self.net_g_ema.invalidate_packed()
-            return
-        optim.ema_update(self._ema_flat, self.optimizer_g.flat_p, decay, modules=[self.net_g_ema])
+        self.packs['g'].blend_shadow(decay)
 
     # ------------------------------------------------------------------ optimisers / schedules
-    def get_optimizer(self, optim_type, params, lr, modules=(), **kwargs):
-        if optim_type == 'Adam':
-            return optim.FlatAdam(params, lr, modules=modules, **kwargs)
-        raise NotImplementedError(f'optimizer {optim_type} is not supperted yet.')
+    def make_adam(self, pack, block):
+        block = dict(block)
+        kind = block.pop('type')
+        if kind != 'Adam':
+            raise NotImplementedError(f'optimizer {kind} is not supperted yet.')
+        return pack.attach_adam(block, self.logger)
 
     def setup_schedulers(self):
-        train_opt = self.opt['train']
-        scheduler_type = train_opt['scheduler'].pop('type')
-        if scheduler_type in ['MultiStepLR', 'MultiStepRestartLR']:
-            cls = lr_scheduler.MultiStepRestartLR
-        elif scheduler_type == 'CosineAnnealingRestartLR':
-            cls = lr_scheduler.CosineAnnealingRestartLR
-        else:
-            raise NotImplementedError(f'Scheduler {scheduler_type} is not implemented yet.')
-        for optimizer in self.optimizers:
-            self.schedulers.append(cls(optimizer, **train_opt['scheduler']))
-
-    def _set_lr(self, lr_groups_l):
-        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
-            for param_group, lr in zip(optimizer.param_groups, lr_groups):
-                param_group['lr'] = lr
-
-    def _get_init_lr(self):
-        return [[v['initial_lr'] for v in optimizer.param_groups] for optimizer in self.optimizers]
+        block = dict(self.opt['train']['scheduler'])
+        kind = block.pop('type')
+        if kind not in _SCHEDULES:
+            raise NotImplementedError(f'Scheduler {kind} is not implemented yet.')
+        self.schedulers = [_SCHEDULES[kind](adam, **block) for adam in self.optimizers]
 
     def update_learning_rate(self, current_iter, warmup_iter=-1):
+        """Schedulers advance from iteration 2 on; below ``warmup_iter`` the rate is initial_lr * iter / warmup_iter."""
         if current_iter > 1:
-            for scheduler in self.schedulers:
-                scheduler.step()
-        if current_iter < warmup_iter:  # linear warm-up
-            init_lr_g_l = self._get_init_lr()
-            self._set_lr([[v / warmup_iter * current_iter for v in init_lr_g] for init_lr_g in init_lr_g_l])
+            for s in self.schedulers:
+                s.step()
+        if current_iter < warmup_iter:
+            ramp = current_iter / warmup_iter
+            for adam in self.optimizers:
+                for group in adam.param_groups:
+                    group['lr'] = group['initial_lr'] * ramp
 
     def get_current_learning_rate(self):
-        return [param_group['lr'] for param_group in self.optimizers[0].param_groups]
+        return [group['lr'] for group in self.optimizers[0].param_groups]
 
-    # ------------------------------------------------------------------ checkpoints (reference file formats)
-    @staticmethod
-    def _save_with_retry(obj, path, what):
-        retry = 3
-        while retry > 0:
-            try:
-                torch.save(obj, path)
-            except Exception as e:  # noqa: BLE001
-                logging.getLogger('basicsr').warning(f'Save {what} error: {e}, remaining retry times: {retry - 1}')
-                time.sleep(1)
-            else:
-                break
-            finally:
-                retry -= 1
-        if retry == 0:
-            raise IOError(f'Cannot save {path}.')
-
+    # ------------------------------------------------------------------ files (formats of base_model.py:170-326)
     @master_only
     def save_network(self, net, net_label, current_iter, param_key='params'):
-        if current_iter == -1:
-            current_iter = 'latest'
-        save_path = os.path.join(self.opt['path']['models'], f'{net_label}_{current_iter}.pth')
-        net = net if isinstance(net, list) else [net]
-        param_key = param_key if isinstance(param_key, list) else [param_key]
-        assert len(net) == len(param_key), 'The lengths of net and param_key should be the same.'
-        save_dict = {}
-        for net_, key_ in zip(net, param_key):
-            sd = OrderedDict()
-            for k, v in self.get_bare_model(net_).state_dict().items():
-                sd[k[7:] if k.startswith('module.') else k] = v.detach().cpu().clone()
-            save_dict[key_] = sd
-        self._save_with_retry(save_dict, save_path, 'model')
+        nets = net if isinstance(net, list) else [net]
+        keys = param_key if isinstance(param_key, list) else [param_key]
+        assert len(nets) == len(keys), 'The lengths of net and param_key should be the same.'
+        tag = 'latest' if current_iter == -1 else current_iter
+        payload = {key: _strip_module_prefix(OrderedDict((k, v.detach().cpu().clone())
+                                                         for k, v in _bare(n).state_dict().items()))
+                   for n, key in zip(nets, keys)}
+        _write_with_retries(payload, os.path.join(self.opt['path']['models'], f'{net_label}_{tag}.pth'), 'model')
 
     def load_network(self, net, load_path, strict=True, param_key='params'):
-        net = self.get_bare_model(net)
-        self.logger.info(f'Loading {net.__class__.__name__} model from {load_path}.')
-        load_net = torch.load(load_path, map_location='cpu', weights_only=False)
+        net = _bare(net)
+        self.logger.info(f'Loading {type(net).__name__} model from {load_path}.')
+        blob = torch.load(load_path, map_location='cpu', weights_only=False)
         if param_key is not None:
-            if param_key not in load_net and 'params' in load_net:
-                param_key = 'params'
+            if param_key not in blob and 'params' in blob:
                 self.logger.info('Loading: params_ema does not exist, use params.')
-            load_net = load_net[param_key]
-        for k, v in deepcopy(load_net).items():
-            if k.startswith('module.'):
-                load_net[k[7:]] = v
-                load_net.pop(k)
+                param_key = 'params'
+            blob = blob[param_key]
+        blob = _strip_module_prefix(blob)
         if not strict:
-            crt = net.state_dict()
-            for k in set(crt) & set(load_net):
-                if crt[k].size() != load_net[k].size():
-                    self.logger.warning(f'Size different, ignore [{k}]: crt_net: {crt[k].shape}; load_net: {load_net[k].shape}')
-                    load_net[k + '.ignore'] = load_net.pop(k)
-        net.load_state_dict(load_net, strict=strict)
+            have = net.state_dict()
+            for k in [k for k in blob if k in have and have[k].shape != blob[k].shape]:
+                self.logger.warning(f'Size different, ignore [{k}]: crt_net: {have[k].shape}; load_net: {blob[k].shape}')
+                blob[k + '.ignore'] = blob.pop(k)
+        net.load_state_dict(blob, strict=strict)
         if hasattr(net, 'invalidate_packed'):
             net.invalidate_packed()
 
     @master_only
     def save_training_state(self, epoch, current_iter):
-        if current_iter != -1:
-            state = {'epoch': epoch, 'iter': current_iter, 'optimizers': [o.state_dict() for o in self.optimizers],
-                     'schedulers': [s.state_dict() for s in self.schedulers]}
-            self._save_with_retry(state, os.path.join(self.opt['path']['training_states'], f'{current_iter}.state'),
-                                  'training state')
+        if current_iter == -1:
+            return
+        state = dict(epoch=epoch, iter=current_iter, optimizers=[a.state_dict() for a in self.optimizers],
+                     schedulers=[s.state_dict() for s in self.schedulers])
+        _write_with_retries(state, os.path.join(self.opt['path']['training_states'], f'{current_iter}.state'),
+                            'training state')
 
     def resume_training(self, resume_state):
-        resume_optimizers = resume_state['optimizers']
-        resume_schedulers = resume_state['schedulers']
-        assert len(resume_optimizers) == len(self.optimizers), 'Wrong lengths of optimizers'
-        assert len(resume_schedulers) == len(self.schedulers), 'Wrong lengths of schedulers'
-        for i, o in enumerate(resume_optimizers):
-            self.optimizers[i].load_state_dict(o)
-        for i, s in enumerate(resume_schedulers):
-            self.schedulers[i].load_state_dict(s)
+        adam_states, schedule_states = resume_state['optimizers'], resume_state['schedulers']
+        assert len(adam_states) == len(self.optimizers), 'Wrong lengths of optimizers'
+        assert len(schedule_states) == len(self.schedulers), 'Wrong lengths of schedulers'
+        for adam, st in zip(self.optimizers, adam_states):
+            adam.load_state_dict(st)
+        for sched, st in zip(self.schedulers, schedule_states):
+            sched.load_state_dict(st)
 
     # ------------------------------------------------------------------ logging
     def reduce_loss_dict(self, loss_dict):
-        """Averages the logged scalars over ranks onto rank 0 (dist.reduce + /world_size, base_model.py:336-347)."""
+        """name -> python float; under data parallelism rank 0 receives the mean over ranks (dist.reduce then
+        / world_size), other ranks keep whatever the reduce left them, as in the reference."""
+        names = list(loss_dict)
+        if not names:
+            return OrderedDict()
         with torch.no_grad():
-            if self.opt['dist']:
-                keys = list(loss_dict.keys())
-                losses = torch.stack([loss_dict[k].detach().float().reshape(()) for k in keys], 0)
-                torch.distributed.reduce(losses, dst=0)
+            vec = torch.stack([loss_dict[n].detach().float().mean() for n in names])
+            if self.distributed:
+                torch.distributed.reduce(vec, dst=0)
                 if self.opt['rank'] == 0:
-                    losses /= self.opt['world_size']
-                loss_dict = {key: loss for key, loss in zip(keys, losses)}
-            log_dict = OrderedDict()
-            for name, value in loss_dict.items():
-                log_dict[name] = value.mean().item()
-            return log_dict
+                    vec /= self.opt['world_size']
+            return OrderedDict(zip(names, vec.tolist()))

@@ -1,128 +1,136 @@
-"""SRModel: generator-only training / testing (PSNR pre-training of RRDBNet).
+"""SRModel: generator-only training / testing (the PSNR pre-training stage of RRDBNet).
 
-Counterpart of basicsr/models/sr_model.py:14-133,204-209 on the HIP path: same option keys, same step order
-(zero_grad -> forward -> pixel loss -> backward -> Adam -> EMA), same log keys."""
-from collections import OrderedDict
-
+Behavioural counterpart of basicsr/models/sr_model.py:14-133,204-209: same option keys (``network_g``,
+``path.pretrain_network_g / strict_load_g``, ``train.{ema_decay, pixel_opt, perceptual_opt, optim_g, scheduler}``),
+same step (zero grads -> forward -> content loss -> backward -> Adam -> EMA), same log keys (``l_pix``, ``l_percep``,
+``l_style``), same checkpoint files.  Structure: the generator is a ``NetPack``; the terms of a loss are collected in a
+``LossBook`` that GAN models extend with their own entries.
+"""
 import os
+from collections import OrderedDict
 
 import torch
 
-from .. import optim
 from ..archs import build_network
 from ..losses import build_loss
 from ..utils.registry import MODEL_REGISTRY
 from .base_model import BaseModel
 
 
+class LossBook:
+    """Ordered ledger of the scalars of one step: every entry is logged, entries flagged ``optimise`` add up to the
+    objective that is back-propagated."""
+
+    def __init__(self):
+        self.entries = OrderedDict()
+        self.objective = None
+
+    def log(self, key, value):
+        self.entries[key] = value
+
+    def charge(self, key, value):
+        self.entries[key] = value
+        self.objective = value if self.objective is None else self.objective + value
+
+
 @MODEL_REGISTRY.register()
 class SRModel(BaseModel):
 
+    log_prefix = 'l_'   # SRGAN / ESRGAN log the generator's content terms as l_g_*
+
     def __init__(self, opt):
         super().__init__(opt)
-        self.net_g = self.model_to_device(build_network(opt['network_g']))
-        self.print_network(self.net_g)
-        load_path = self.opt['path'].get('pretrain_network_g', None)
-        if load_path is not None:
-            self.load_network(self.net_g, load_path, self.opt['path'].get('strict_load_g', True))
+        self.gen = self.adopt('g', build_network(opt['network_g']))
+        self.net_g = self.gen.net
         if self.is_train:
             self.init_training_settings()
+        self.align_replicas()
 
-    def _init_ema(self, train_opt):
-        self.ema_decay = train_opt.get('ema_decay', 0)
-        if self.ema_decay > 0:
-            self.logger.info(f'Use Exponential Moving Average with decay: {self.ema_decay}')
-            self.net_g_ema = build_network(self.opt['network_g']).to(self.device)
-            load_path = self.opt['path'].get('pretrain_network_g', None)
-            if load_path is not None:
-                self.load_network(self.net_g_ema, load_path, self.opt['path'].get('strict_load_g', True), 'params_ema')
-            self.net_g_ema.eval()
-            self._ema_pending_copy = load_path is None
-
-    def _finish_ema(self):
-        """After the optimiser built net_g's arena: flatten the EMA copy the same way."""
-        if self.ema_decay > 0:
-            self._ema_flat = optim.flatten_parameters(self.net_g_ema)
-            if self._ema_pending_copy:
-                self.model_ema(0)  # copy net_g weight
-
+    # ------------------------------------------------------------------ set-up
     def init_training_settings(self):
+        cfg = self.opt['train']
         self.net_g.train()
-        train_opt = self.opt['train']
-        self._init_ema(train_opt)
-        self.cri_pix = build_loss(train_opt['pixel_opt']).to(self.device) if train_opt.get('pixel_opt') else None
-        # perceptual loss (losses.py:249-356 on HIP VGG features; the frozen VGG is not optimised)
-        self.cri_perceptual = (build_loss(train_opt['perceptual_opt']).to(self.device)
-                               if train_opt.get('perceptual_opt') else None)
+        self._build_content_losses(cfg)
         if self.cri_pix is None and self.cri_perceptual is None:
             raise ValueError('Both pixel and perceptual losses are None.')
         self.setup_optimizers()
         self.setup_schedulers()
-        self._finish_ema()
+        self._build_shadow(cfg)
+
+    def _build_content_losses(self, cfg):
+        def criterion(key):
+            return build_loss(cfg[key]).to(self.device) if cfg.get(key) else None
+        self.cri_pix = criterion('pixel_opt')
+        self.cri_perceptual = criterion('perceptual_opt')   # frozen VGG features (losses/perceptual_loss.py)
+
+    def _build_shadow(self, cfg):
+        """``train.ema_decay`` > 0: a second generator that trails the trained one.  It starts from the checkpoint's
+        ``params_ema`` when a pretrained file is given, else as a copy of the live weights (sr_model.py:38-50)."""
+        self.ema_decay = cfg.get('ema_decay', 0)
+        if not self.ema_decay > 0:
+            return
+        self.logger.info(f'Use Exponential Moving Average with decay: {self.ema_decay}')
+        twin = build_network(self.opt['network_g']).to(self.device)
+        source = self.opt['path'].get('pretrain_network_g')
+        if source is not None:
+            self.load_network(twin, source, self.opt['path'].get('strict_load_g', True), 'params_ema')
+        self.gen.attach_shadow(twin)
+        self.net_g_ema = twin
+        if source is None:
+            self.gen.blend_shadow(0)
 
     def setup_optimizers(self):
-        train_opt = self.opt['train']
-        optim_params = []
-        for k, v in self.net_g.named_parameters():
-            if v.requires_grad:
-                optim_params.append(v)
-            else:
-                self.logger.warning(f'Params {k} will not be optimized.')
-        optim_type = train_opt['optim_g'].pop('type')
-        self.optimizer_g = self.get_optimizer(optim_type, optim_params, modules=[self.net_g], **train_opt['optim_g'])
-        self.optimizers.append(self.optimizer_g)
+        self.optimizer_g = self.make_adam(self.gen, self.opt['train']['optim_g'])
 
+    # ------------------------------------------------------------------ one step
     def feed_data(self, data):
-        self.lq = data['lq'].to(self.device)
-        if 'gt' in data:
-            self.gt = data['gt'].to(self.device)
+        for key in ('lq', 'gt'):
+            if key in data:
+                setattr(self, key, data[key].to(self.device))
 
-    def _step(self, optimizer):
-        """DP gradient exchange (one arena all-reduce) + fused Adam."""
-        scale = optimizer.all_reduce_grads() if self.opt['dist'] else 1.0
-        optimizer.step(grad_scale=scale)
+    def content_terms(self, book):
+        """Pixel / perceptual / style terms of the generator objective, in the reference's order."""
+        pre = self.log_prefix
+        if self.cri_pix:
+            book.charge(pre + 'pix', self.cri_pix(self.output, self.gt))
+        if self.cri_perceptual:
+            percep, style = self.cri_perceptual(self.output, self.gt)
+            if percep is not None:
+                book.charge(pre + 'percep', percep)
+            if style is not None:
+                book.charge(pre + 'style', style)
+
+    def finish_step(self, book):
+        self.log_dict = self.reduce_loss_dict(book.entries)
+        if self.ema_decay > 0:
+            self.gen.blend_shadow(self.ema_decay)
 
     def optimize_parameters(self, current_iter):
-        self.optimizer_g.zero_grad()
+        self.refresh_buffers()
+        book = LossBook()
+        self.gen.clear_grads()
         self.output = self.net_g(self.lq)
-        loss_dict = OrderedDict()
-        l_total = 0
-        if self.cri_pix:  # sr_model.py:97-108
-            l_pix = self.cri_pix(self.output, self.gt)
-            l_total = l_total + l_pix
-            loss_dict['l_pix'] = l_pix
-        if self.cri_perceptual:
-            l_percep, l_style = self.cri_perceptual(self.output, self.gt)
-            if l_percep is not None:
-                l_total = l_total + l_percep
-                loss_dict['l_percep'] = l_percep
-            if l_style is not None:
-                l_total = l_total + l_style
-                loss_dict['l_style'] = l_style
-        l_total.backward()
-        self._step(self.optimizer_g)
-        self.log_dict = self.reduce_loss_dict(loss_dict)
-        if self.ema_decay > 0:
-            self.model_ema(decay=self.ema_decay)
+        self.content_terms(book)
+        book.objective.backward()
+        self.gen.update(self.distributed)
+        self.finish_step(book)
 
+    # ------------------------------------------------------------------ inference / validation
     def test(self):
-        if hasattr(self, 'net_g_ema'):
-            self.net_g_ema.eval()
-            with torch.no_grad():
-                self.output = self.net_g_ema(self.lq)
-        else:
-            self.net_g.eval()
-            with torch.no_grad():
-                self.output = self.net_g(self.lq)
+        """One forward without autograd, through the EMA shadow when there is one (sr_model.py:120-129)."""
+        runner = getattr(self, 'net_g_ema', None)
+        restore = runner is None
+        if restore:
+            runner = self.net_g
+        runner.eval()
+        with torch.no_grad():
+            self.output = runner(self.lq)
+        if restore:
             self.net_g.train()
 
-    # ------------------------------------------------------------------ validation (sr_model.py:131-184)
     def validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
-        """base_model.py:39-48: rank 0 validates when distributed."""
-        if self.opt['dist']:
-            if self.opt['rank'] == 0:
-                self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
-        else:
+        """Rank 0 validates alone under data parallelism (base_model.py:39-48)."""
+        if not self.distributed or self.opt['rank'] == 0:
             self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
 
     def nondist_validation(self, dataloader, current_iter, tb_logger=None, save_img=False):
@@ -181,16 +189,16 @@ class SRModel(BaseModel):
                     tb_logger.add_scalar(f'metrics/{m}', v, current_iter)
 
     def get_current_visuals(self):
-        out_dict = OrderedDict()
-        out_dict['lq'] = self.lq.detach().cpu()
-        out_dict['result'] = self.output.detach().cpu()
+        shown = OrderedDict(lq=self.lq.detach().cpu(), result=self.output.detach().cpu())
         if hasattr(self, 'gt'):
-            out_dict['gt'] = self.gt.detach().cpu()
-        return out_dict
+            shown['gt'] = self.gt.detach().cpu()
+        return shown
 
+    # ------------------------------------------------------------------ files
     def save(self, epoch, current_iter):
-        if hasattr(self, 'net_g_ema'):
-            self.save_network([self.net_g, self.net_g_ema], 'net_g', current_iter, param_key=['params', 'params_ema'])
+        """net_g_<iter>.pth holds ``params`` (+ ``params_ema`` when the shadow exists), then the training state."""
+        if self.gen.shadow is not None:
+            self.save_network([self.net_g, self.gen.shadow], 'net_g', current_iter, param_key=['params', 'params_ema'])
         else:
             self.save_network(self.net_g, 'net_g', current_iter)
         self.save_training_state(epoch, current_iter)

@@ -1,106 +1,119 @@
-"""SRGANModel: generator + discriminator with the plain (non-relativistic) GAN loss.
+"""SRGANModel: generator + discriminator, one adversarial step driver for both GAN formulations of the path.
 
-Counterpart of basicsr/models/srgan_model.py:15-143: same option keys, requires_grad toggling on D (:81-83,
-:111-113), step order (G: pix + gan -> backward -> Adam; D: real backward, fake backward -> Adam), log keys."""
-from collections import OrderedDict
+Behavioural counterpart of basicsr/models/srgan_model.py:15-143 (plain GAN loss) and, through the ``relativistic``
+switch that ESRGANModel turns on, of basicsr/models/esrgan_model.py:12-83 (relativistic average GAN).  What is kept
+is what a user of the reference can observe: option keys (``network_d``, ``path.pretrain_network_d / strict_load_d``,
+``train.{optim_d, gan_opt, net_d_iters, net_d_init_iters}``), the order and number of discriminator forwards (they
+move BatchNorm statistics), which logits carry a graph, the log keys and the checkpoint files.
 
+A step has two phases:
+
+``_generator_phase``  D frozen; G forward; when it is G's turn: content terms + adversarial term -> backward -> Adam.
+``_critic_phase``     D live; real and fake are back-propagated by two separate backward calls that accumulate in the
+                      gradient arena, which is exchanged ONCE before D's Adam (the reference's DDP exchanges twice;
+                      sums are the same).
+"""
 import torch
 
 from .. import hip_autograd as A
 from ..archs import build_network
 from ..losses import build_loss
 from ..utils.registry import MODEL_REGISTRY
-from .sr_model import SRModel
+from .sr_model import LossBook, SRModel
 
 
 @MODEL_REGISTRY.register()
 class SRGANModel(SRModel):
 
+    log_prefix = 'l_g_'
+    relativistic = False
+
+    # ------------------------------------------------------------------ set-up
     def init_training_settings(self):
-        train_opt = self.opt['train']
-        self._init_ema(train_opt)
-        self.net_d = self.model_to_device(build_network(self.opt['network_d']))
-        self.print_network(self.net_d)
-        load_path = self.opt['path'].get('pretrain_network_d', None)
-        if load_path is not None:
-            self.load_network(self.net_d, load_path, self.opt['path'].get('strict_load_d', True))
+        cfg = self.opt['train']
+        self.critic = self.adopt('d', build_network(self.opt['network_d']))
+        self.net_d = self.critic.net
         self.net_g.train()
         self.net_d.train()
-        self.cri_pix = build_loss(train_opt['pixel_opt']).to(self.device) if train_opt.get('pixel_opt') else None
-        # perceptual loss (losses.py:249-356 on HIP VGG features; the frozen VGG is not optimised)
-        self.cri_perceptual = (build_loss(train_opt['perceptual_opt']).to(self.device)
-                               if train_opt.get('perceptual_opt') else None)
-        if train_opt.get('gan_opt'):
-            self.cri_gan = build_loss(train_opt['gan_opt']).to(self.device)
-        self.net_d_iters = train_opt.get('net_d_iters', 1)
-        self.net_d_init_iters = train_opt.get('net_d_init_iters', 0)
+        self._build_content_losses(cfg)
+        if cfg.get('gan_opt'):
+            self.cri_gan = build_loss(cfg['gan_opt']).to(self.device)
+        self.net_d_iters = cfg.get('net_d_iters', 1)
+        self.net_d_init_iters = cfg.get('net_d_init_iters', 0)
         self.setup_optimizers()
         self.setup_schedulers()
-        self._finish_ema()
+        self._build_shadow(cfg)
 
     def setup_optimizers(self):
-        train_opt = self.opt['train']
-        optim_type = train_opt['optim_g'].pop('type')
-        self.optimizer_g = self.get_optimizer(optim_type, self.net_g.parameters(), modules=[self.net_g],
-                                              **train_opt['optim_g'])
-        self.optimizers.append(self.optimizer_g)
-        optim_type = train_opt['optim_d'].pop('type')
-        self.optimizer_d = self.get_optimizer(optim_type, self.net_d.parameters(), modules=[self.net_d],
-                                              **train_opt['optim_d'])
-        self.optimizers.append(self.optimizer_d)
+        self.optimizer_g = self.make_adam(self.gen, self.opt['train']['optim_g'])
+        self.optimizer_d = self.make_adam(self.critic, self.opt['train']['optim_d'])
 
-    def _g_active(self, current_iter):
-        return current_iter % self.net_d_iters == 0 and current_iter > self.net_d_init_iters
+    def generator_turn(self, current_iter):
+        """G trains every ``net_d_iters`` iterations once ``net_d_init_iters`` have passed."""
+        return current_iter > self.net_d_init_iters and current_iter % self.net_d_iters == 0
+
+    # ------------------------------------------------------------------ adversarial terms
+    def _fool_critic(self):
+        """Generator-side GAN term on ``self.output`` (graph into G)."""
+        if not self.relativistic:
+            return self.cri_gan(self.net_d(self.output), True, is_disc=False)
+        with torch.no_grad():                      # esrgan_model.py:38 - real logits are constants for G
+            on_real = self.net_d(self.gt)
+        on_fake = self.net_d(self.output)
+        gan = self.cri_gan.relativistic
+        return (gan(on_real, on_fake, False, is_disc=False) + gan(on_fake, on_real, True, is_disc=False)) / 2
+
+    def _critic_phase(self, book):
+        fake_img = self.output.detach()
+        if not self.relativistic:
+            on_real = self.net_d(self.gt)
+            loss_real = self.cri_gan(on_real, True, is_disc=True)
+            book.log('l_d_real', loss_real)
+            book.log('out_d_real', A.mean(on_real))
+            loss_real.backward()
+            on_fake = self.net_d(fake_img)
+            loss_fake = self.cri_gan(on_fake, False, is_disc=True)
+            book.log('l_d_fake', loss_fake)
+            book.log('out_d_fake', A.mean(on_fake))
+            loss_fake.backward()
+            return
+        gan = self.cri_gan.relativistic
+        with torch.no_grad():   # the reference detaches this forward's result (:65); BatchNorm statistics still move
+            fake_const = self.net_d(fake_img)
+        on_real = self.net_d(self.gt)
+        loss_real = gan(on_real, fake_const, True, is_disc=True) * 0.5
+        loss_real.backward()
+        on_fake = self.net_d(fake_img)
+        loss_fake = gan(on_fake, on_real.detach(), False, is_disc=True) * 0.5
+        loss_fake.backward()
+        book.log('l_d_real', loss_real)
+        book.log('l_d_fake', loss_fake)
+        book.log('out_d_real', A.mean(on_real))
+        book.log('out_d_fake', A.mean(on_fake))
+
+    # ------------------------------------------------------------------ one step
+    def _generator_phase(self, book, current_iter):
+        self.critic.freeze(True)
+        self.gen.clear_grads()
+        self.output = self.net_g(self.lq)
+        if not self.generator_turn(current_iter):
+            return
+        self.content_terms(book)
+        book.charge('l_g_gan', self._fool_critic())
+        book.objective.backward()
+        self.gen.update(self.distributed)
 
     def optimize_parameters(self, current_iter):
-        for p in self.net_d.parameters():
-            p.requires_grad = False
-        self.optimizer_g.zero_grad()
-        self.output = self.net_g(self.lq)
-        loss_dict = OrderedDict()
-        if self._g_active(current_iter):
-            l_g_total = 0
-            if self.cri_pix:
-                l_g_pix = self.cri_pix(self.output, self.gt)
-                l_g_total = l_g_total + l_g_pix
-                loss_dict['l_g_pix'] = l_g_pix
-            if self.cri_perceptual:  # sr(gan)_model.py: perceptual (and style) terms of the generator loss
-                l_g_percep, l_g_style = self.cri_perceptual(self.output, self.gt)
-                if l_g_percep is not None:
-                    l_g_total = l_g_total + l_g_percep
-                    loss_dict['l_g_percep'] = l_g_percep
-                if l_g_style is not None:
-                    l_g_total = l_g_total + l_g_style
-                    loss_dict['l_g_style'] = l_g_style
-            fake_g_pred = self.net_d(self.output)
-            l_g_gan = self.cri_gan(fake_g_pred, True, is_disc=False)
-            l_g_total = l_g_total + l_g_gan
-            loss_dict['l_g_gan'] = l_g_gan
-            l_g_total.backward()
-            self._step(self.optimizer_g)
+        self.refresh_buffers()
+        book = LossBook()
+        self._generator_phase(book, current_iter)
+        self.critic.freeze(False)
+        self.critic.clear_grads()
+        self._critic_phase(book)
+        self.critic.update(self.distributed)
+        self.finish_step(book)
 
-        for p in self.net_d.parameters():
-            p.requires_grad = True
-        self.optimizer_d.zero_grad()
-        real_d_pred = self.net_d(self.gt)
-        l_d_real = self.cri_gan(real_d_pred, True, is_disc=True)
-        loss_dict['l_d_real'] = l_d_real
-        loss_dict['out_d_real'] = A.mean(real_d_pred)
-        l_d_real.backward()
-        fake_d_pred = self.net_d(self.output.detach())
-        l_d_fake = self.cri_gan(fake_d_pred, False, is_disc=True)
-        loss_dict['l_d_fake'] = l_d_fake
-        loss_dict['out_d_fake'] = A.mean(fake_d_pred)
-        l_d_fake.backward()
-        self._step(self.optimizer_d)
-        self.log_dict = self.reduce_loss_dict(loss_dict)
-        if self.ema_decay > 0:
-            self.model_ema(decay=self.ema_decay)
-
+    # ------------------------------------------------------------------ files
     def save(self, epoch, current_iter):
-        if hasattr(self, 'net_g_ema'):
-            self.save_network([self.net_g, self.net_g_ema], 'net_g', current_iter, param_key=['params', 'params_ema'])
-        else:
-            self.save_network(self.net_g, 'net_g', current_iter)
         self.save_network(self.net_d, 'net_d', current_iter)
-        self.save_training_state(epoch, current_iter)
+        super().save(epoch, current_iter)

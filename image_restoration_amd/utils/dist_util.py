@@ -1,7 +1,8 @@
-"""Process-group set-up: one process per GPU, torch.distributed over RCCL (backend 'nccl' IS RCCL on ROCm).
+"""Process-group set-up: one process per GPU, ``torch.distributed`` over RCCL (backend name 'nccl' on ROCm).
 
-Counterpart of basicsr/utils/dist_util.py (init_dist :10-18, _init_dist_pytorch :21-25, get_dist_info :60-71,
-master_only :74-82).  The slurm launcher is not reproduced (scheduler plumbing, out of scope)."""
+Behaviour of basicsr/utils/dist_util.py for the ``pytorch`` launcher (init_dist :10-25, get_dist_info :60-71, master_only :74-82);
+the slurm launcher is scheduler plumbing and out of scope.  The rendezvous address defaults to 127.0.0.1 (single node; container
+host names may not resolve)."""
 import functools
 import os
 
@@ -10,28 +11,29 @@ import torch.distributed as dist
 
 
 def init_dist(launcher='pytorch', backend='nccl', **kwargs):
+    """Reads RANK (set by torch.distributed.run) and joins the default process group; with RCCL the rank's GPU is
+    ``rank mod visible devices``."""
     if launcher != 'pytorch':
         raise ValueError(f'Invalid launcher type: {launcher}')
-    rank = int(os.environ['RANK'])
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend == 'nccl':
-        num_gpus = torch.cuda.device_count()
-        torch.cuda.set_device(rank % num_gpus)
+        torch.cuda.set_device(int(os.environ['RANK']) % torch.cuda.device_count())
     dist.init_process_group(backend=backend, **kwargs)
 
 
 def get_dist_info():
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    """(rank, world size); (0, 1) outside a process group."""
+    active = dist.is_available() and dist.is_initialized()
+    return (dist.get_rank(), dist.get_world_size()) if active else (0, 1)
 
 
 def master_only(func):
+    """The wrapped function runs on rank 0 and is a no-op (returning None) elsewhere."""
 
     @functools.wraps(func)
-    def wrapper(*args, **kwargs):
-        rank, _ = get_dist_info()
-        if rank == 0:
-            return func(*args, **kwargs)
+    def on_rank0(*args, **kwargs):
+        if get_dist_info()[0] != 0:
+            return None
+        return func(*args, **kwargs)
 
-    return wrapper
+    return on_rank0

@@ -31,7 +31,7 @@ def _rel(a, b):
 ])
 def test_vgg_features_and_input_gradient(cuda, vgg_type, layers, norm, rng):
     torch.manual_seed(0)
-    net = ira.build_network(dict(type='VGGFeatureExtractor', layer_name_list=layers, vgg_type=vgg_type, use_input_norm=norm,
+    net = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=layers, vgg_type=vgg_type, use_input_norm=norm,
                                  range_norm=rng)).to(cuda)
     assert not any(p.requires_grad for p in net.parameters())
     sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items() if k.startswith('vgg_net.')}
@@ -52,7 +52,7 @@ def test_vgg_features_and_input_gradient(cuda, vgg_type, layers, norm, rng):
 def test_perceptual_loss_value_and_gradient(cuda):
     from image_restoration_amd.losses import build_loss
     torch.manual_seed(1)
-    crit = build_loss(dict(type='PerceptualLoss', layer_weights={'conv3_4': 0.5, 'conv5_4': 1.0}, vgg_type='vgg19',
+    crit = build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights={'conv3_4': 0.5, 'conv5_4': 1.0}, vgg_type='vgg19',
                            use_input_norm=True, range_norm=False, perceptual_weight=1.0, style_weight=0, criterion='l1')).to(cuda)
     sd = {k: v.detach().cpu().double() for k, v in crit.vgg.state_dict().items() if k.startswith('vgg_net.')}
     x, gt = torch.rand(2, 3, 64, 48), torch.rand(2, 3, 64, 48)
@@ -66,7 +66,7 @@ def test_perceptual_loss_value_and_gradient(cuda):
     ref.backward()
     assert float((xc.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < 3e-2
     with pytest.raises(NotImplementedError):
-        build_loss(dict(type='PerceptualLoss', layer_weights={'conv5_4': 1.0}, criterion='l2'))
+        build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights={'conv5_4': 1.0}, criterion='l2'))
 
 
 @pytest.mark.parametrize('criterion', ['l1', 'fro'])
@@ -75,7 +75,7 @@ def test_style_term_and_fro_criterion(cuda, criterion):
     from image_restoration_amd.losses import build_loss
     torch.manual_seed(2)
     lw = {'conv2_2': 1.0, 'conv4_4': 0.25}
-    crit = build_loss(dict(type='PerceptualLoss', layer_weights=lw, vgg_type='vgg19', perceptual_weight=0.5, style_weight=20.0,
+    crit = build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights=lw, vgg_type='vgg19', perceptual_weight=0.5, style_weight=20.0,
                            criterion=criterion)).to(cuda)
     sd = {k: v.detach().cpu().double() for k, v in crit.vgg.state_dict().items() if k.startswith('vgg_net.')}
     x, gt = torch.rand(2, 3, 48, 64), torch.rand(2, 3, 48, 64)
@@ -87,7 +87,7 @@ def test_style_term_and_fro_criterion(cuda, criterion):
     (lp + ls).backward()
     (rp + rs).backward()
     assert float((xc.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < 3e-2  # ReLU-flip bound, see above
-    only_style = build_loss(dict(type='PerceptualLoss', layer_weights=lw, perceptual_weight=0, style_weight=1.0)).to(cuda)
+    only_style = build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights=lw, perceptual_weight=0, style_weight=1.0)).to(cuda)
     lp0, ls0 = only_style(xc.detach(), gt.to(cuda))
     assert lp0 is None and float(ls0) > 0
 
@@ -102,8 +102,8 @@ def test_vgg_features_bf16_vs_fp32_path(cuda):
     from image_restoration_amd.losses import build_loss
     torch.manual_seed(4)
     names = ['relu1_1', 'pool1', 'conv3_4', 'conv5_4']
-    f32 = ira.build_network(dict(type='VGGFeatureExtractor', layer_name_list=names, vgg_type='vgg19')).to(cuda)
-    f16 = ira.build_network(dict(type='VGGFeatureExtractor', layer_name_list=names, vgg_type='vgg19', compute_dtype='bf16')).to(cuda)
+    f32 = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=names, vgg_type='vgg19')).to(cuda)
+    f16 = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=names, vgg_type='vgg19', compute_dtype='bf16')).to(cuda)
     f16.load_state_dict(f32.state_dict())
     x = torch.rand(2, 3, 64, 80, device=cuda)
     a, b = f32(x), f16(x)
@@ -111,8 +111,8 @@ def test_vgg_features_bf16_vs_fp32_path(cuda):
         assert b[k].dtype == torch.float32 and b[k].shape == a[k].shape
         assert float((a[k] - b[k]).norm() / a[k].norm()) < 2e-2, k
     lw = {'conv3_4': 0.5, 'conv5_4': 1.0}
-    c32 = build_loss(dict(type='PerceptualLoss', layer_weights=lw, vgg_type='vgg19')).to(cuda)
-    c16 = build_loss(dict(type='PerceptualLoss', layer_weights=lw, vgg_type='vgg19', compute_dtype='bf16')).to(cuda)
+    c32 = build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights=lw, vgg_type='vgg19')).to(cuda)
+    c16 = build_loss(dict(type='PerceptualLoss', allow_random_init=True, layer_weights=lw, vgg_type='vgg19', compute_dtype='bf16')).to(cuda)
     c16.load_state_dict(c32.state_dict())
     gt = torch.rand(2, 3, 64, 80, device=cuda)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
@@ -125,11 +125,27 @@ def test_vgg_features_bf16_vs_fp32_path(cuda):
     assert float((ga - gb).norm() / ga.norm()) < 0.40 and float(ga @ gb / (ga.norm() * gb.norm())) > 0.93
 
 
+def test_missing_pretrained_weights_are_refused_and_random_features_agree_across_seeds(cuda):
+    """No ImageNet file and no opt-in: constructing the extractor fails (the reference would download through torchvision; silent
+    random features would make l_g_percep meaningless).  With the opt-in, the random extractor does not depend on the process seed
+    (ranks of a data-parallel job are seeded manual_seed + rank and must optimise the same loss)."""
+    with pytest.raises(FileNotFoundError):
+        ira.build_network(dict(type='VGGFeatureExtractor', layer_name_list=['conv2_2'], vgg_type='vgg19'))
+    from image_restoration_amd.losses import build_loss
+    with pytest.raises(FileNotFoundError):
+        build_loss(dict(type='PerceptualLoss', layer_weights={'conv5_4': 1.0}))
+    torch.manual_seed(10)
+    a = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=['conv2_2'], vgg_type='vgg19'))
+    torch.manual_seed(11)
+    b = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=['conv2_2'], vgg_type='vgg19'))
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+
+
 def test_torchvision_state_dict_keys_load(cuda):
     """A torchvision ``features.N.*`` state_dict (N = index in the full VGG19 features stack) lands on the right layers."""
     from image_restoration_amd.archs.vgg_arch import layer_names
     names = layer_names('vgg19')
-    net = ira.build_network(dict(type='VGGFeatureExtractor', layer_name_list=['conv2_2'], vgg_type='vgg19'))
+    net = ira.build_network(dict(type='VGGFeatureExtractor', allow_random_init=True, layer_name_list=['conv2_2'], vgg_type='vgg19'))
     tv = {}
     for idx, name in enumerate(names):
         if name.startswith('conv'):
@@ -148,7 +164,7 @@ def test_esrgan_step_with_perceptual_loss(cuda):
     from test_training_gpu import _opt
     from image_restoration_amd.models import build_model
     opt = _opt('ESRGANModel')
-    opt['train']['perceptual_opt'] = dict(type='PerceptualLoss', layer_weights={'conv5_4': 1}, vgg_type='vgg19', use_input_norm=True,
+    opt['train']['perceptual_opt'] = dict(type='PerceptualLoss', allow_random_init=True, layer_weights={'conv5_4': 1}, vgg_type='vgg19', use_input_norm=True,
                                           range_norm=False, perceptual_weight=1.0, style_weight=0, criterion='l1')
     model = build_model(opt)
     g = torch.Generator().manual_seed(0)

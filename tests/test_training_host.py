@@ -119,23 +119,37 @@ def test_models_build_from_reference_schema_and_checkpoint_roundtrip(tmp_path):
 
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
+    from image_restoration_amd.models import build_model
+    from image_restoration_amd.utils.options import set_random_seed
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.manual_seed(0)  # same initial weights on every rank, like DDP's broadcast
-    net = ira.build_network(dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, num_feat=16, num_block=1, num_grow_ch=8))
-    opt = optim.FlatAdam(net.parameters(), 1e-3, modules=[net])
-    opt.zero_grad()
-    opt.flat_g.fill_(float(rank + 1))  # stands for this rank's local gradient
-    scale = opt.all_reduce_grads()
-    # loss logging: reduce to rank 0 then / world (base_model.py:336-347)
-    from image_restoration_amd.models.base_model import BaseModel
-    bm = BaseModel(dict(num_gpu=0, is_train=False, dist=True, rank=rank, world_size=world))
-    log = bm.reduce_loss_dict({'l': torch.tensor(float(rank + 1))})
-    q.put((rank, float(opt.flat_g[0]), scale, float(opt.flat_g.min()), float(opt.flat_g.max()), log['l']))
+    set_random_seed(11 + rank)  # utils/options.py: manual_seed + rank, so the ranks draw DIFFERENT initial weights
+    probe = float(torch.rand(1))
+    opt = _opt('ESRGANModel')
+    opt.update(dist=True, rank=rank, world_size=world)
+    model = build_model(opt)    # ends with BaseModel.align_replicas(): rank 0's parameters, buffers and EMA shadow everywhere
+    digest = []
+    for label, pack in model.packs.items():
+        for t in pack.state_tensors():
+            digest.append((label, tuple(t.shape), float(t.double().sum()), float(t.double().abs().sum())))
+    # a buffer that drifted on one rank comes back with refresh_buffers() (DDP broadcast_buffers semantics)
+    model.net_d.bn0_1.running_mean.add_(float(rank))
+    model.refresh_buffers()
+    drift = float(model.net_d.bn0_1.running_mean.abs().max())
+    opt_g = model.optimizer_g
+    opt_g.zero_grad()
+    opt_g.flat_g.fill_(float(rank + 1))  # stands for this rank's local gradient
+    scale = opt_g.all_reduce_grads()
+    log = model.reduce_loss_dict({'l': torch.tensor(float(rank + 1))})  # reduce to rank 0 then / world (base_model.py:336-347)
+    q.put((rank, float(opt_g.flat_g[0]), scale, float(opt_g.flat_g.min()), float(opt_g.flat_g.max()), log['l'], probe, digest, drift))
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradient_exchange_world2():
+def test_data_parallel_replica_alignment_and_gradient_exchange_world2():
+    """Two gloo ranks seeded differently build ESRGANModel (G + EMA shadow + BatchNorm discriminator) from scratch: every parameter
+    arena, shadow arena and buffer is identical across ranks after construction (what DDP's constructor broadcast gives the
+    reference, base_model.py:70-73); the gradient arena is SUM-reduced with the mean folded into the update; logged losses are
+    averaged onto rank 0."""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -143,10 +157,13 @@ def test_data_parallel_gradient_exchange_world2():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, g0, scale, gmin, gmax, l in res:
+    for rank, g0, scale, gmin, gmax, l, probe, digest, drift in res:
         assert g0 == 3.0 and gmin == 3.0 and gmax == 3.0 and scale == 0.5  # sum over ranks, mean applied in the update
+        assert drift == 0.0                                                # rank 1's +1 drift was overwritten by rank 0's zeros
+    assert res[0][6] != res[1][6]                 # the ranks' random streams differ ...
+    assert res[0][7] == res[1][7] and len(res[0][7]) > 20   # ... their networks do not
     assert res[0][5] == 1.5  # rank 0 holds the mean of the logged loss

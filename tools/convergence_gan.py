@@ -18,7 +18,7 @@ def run(dtype, iters):
                train=dict(ema_decay=0, optim_g=dict(adam), optim_d=dict(adam),
                           scheduler=dict(type='MultiStepLR', milestones=[10 ** 6], gamma=0.5), total_iter=iters, warmup_iter=-1,
                           pixel_opt=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
-                          perceptual_opt=dict(type='PerceptualLoss', layer_weights={'conv3_4': 1.0}, vgg_type='vgg19', perceptual_weight=0.05,
+                          perceptual_opt=dict(type='PerceptualLoss', allow_random_init=True, layer_weights={'conv3_4': 1.0}, vgg_type='vgg19', perceptual_weight=0.05,
                                               style_weight=0, criterion='l1', compute_dtype=dtype),
                           gan_opt=dict(type='GANLoss', gan_type='vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight=5e-3),
                           net_d_iters=1, net_d_init_iters=0))

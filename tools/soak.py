@@ -12,7 +12,7 @@ opt = dict(name='soak', model_type='ESRGANModel', scale=4, num_gpu=1, dist=False
            path=dict(pretrain_network_g=None, strict_load_g=True, pretrain_network_d=None),
            train=dict(ema_decay=0.999, optim_g=dict(adam), optim_d=dict(adam), scheduler=dict(type='MultiStepLR', milestones=[10 ** 6], gamma=0.5),
                       total_iter=300, warmup_iter=-1, pixel_opt=dict(type='L1Loss', loss_weight=1e-2, reduction='mean'),
-                      perceptual_opt=dict(type='PerceptualLoss', layer_weights={'conv5_4': 1.0}, vgg_type='vgg19', perceptual_weight=1.0, style_weight=0, criterion='l1', compute_dtype='bf16'),
+                      perceptual_opt=dict(type='PerceptualLoss', allow_random_init=True, layer_weights={'conv5_4': 1.0}, vgg_type='vgg19', perceptual_weight=1.0, style_weight=0, criterion='l1', compute_dtype='bf16'),
                       gan_opt=dict(type='GANLoss', gan_type='vanilla', real_label_val=1.0, fake_label_val=0.0, loss_weight=5e-3), net_d_iters=1, net_d_init_iters=0))
 model = build_model(opt)
 mem = []
