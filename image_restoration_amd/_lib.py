@@ -199,6 +199,9 @@ class LaunchRecord(C.Structure):
 
 
 SIGNATURES.update({
+    'sr_patch_augment_u8_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float), C.c_void_p]),
     'sr_profile_start': (C.c_int, [C.c_int]),
     'sr_profile_stop': (C.c_int, [C.POINTER(LaunchRecord), C.c_int, C.POINTER(C.c_int)]),
     'sr_kernel_name': (C.c_char_p, [C.c_int]),

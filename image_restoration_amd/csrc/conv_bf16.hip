@@ -12,6 +12,14 @@
 // same with an 8-byte bf16x4 store.  Per chunk a wave issues 9*(COT+PT) ds_read_b128 for 9*COT*PT MFMAs of 32
 // cycles: with COT = 2, PT = 4 that is 0.75 reads per MFMA (LDS limit: 2).  The kernel is fed by L2->LDS traffic:
 // 37.6 KB per 9.4 MFLOP chunk of a 16x32x64 tile = 251 FLOP/B.
+//
+// LDS bank swizzle.  A lane reads 16 B of a 32-byte pixel, so the 32 lanes of one half (same h) stride 32 B and a
+// ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}) would hit every 16-byte bank slot twice: PMC of the
+// unswizzled kernel showed SQ_LDS_BANK_CONFLICT = exactly half of SQ_LDS_IDX_ACTIVE, and with 0.6 reads per MFMA the LDS
+// array (7.8 us per conv1-4 launch per CU) was busier than the matrix pipe (6.7 us).  Both LDS images therefore store the
+// two 16-byte halves of pixel / cout number c in swapped order when bit 3 of c is set: lanes 8 apart then fall on
+// different slots and every group covers all 64 banks.  The swap is applied by the LDS-DMA source address (the lane that
+// fills unit q fetches the half that belongs there), so global reads stay whole 32-byte pixels.
 #include "sr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool valid = (pix < XPIX) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     const int sy = gy >> p.src_shift, sx = gx >> p.src_shift;
-    xoff[r] = valid ? ((sy * p.in_w + sx) * 32 + half * 16) : -1;
+    xoff[r] = valid ? ((sy * p.in_w + sx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : -1;  // bank swizzle (header)
   }
 
   auto stage = [&](int buf, int cb) {
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
       const int u = r * NW + wave;
       if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : p.zero, xs + u * 1024);
     }
-    const char* wsrc = wg + (size_t)cb * WBYTES + lane * 16;
+    const char* wsrc = wg + (size_t)cb * WBYTES + (lane ^ ((lane >> 4) & 1)) * 16;  // unit (cout i, half) <- half ^ bit3(i)
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
       const int u = r * NW + wave;
@@ -125,18 +133,23 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  const int xlane = ((wave * PT) * XROW + j) * 32 + h * 16;
-  const int wlane = j * 32 + h * 16;
+  // byte offset of this lane's B operand at column offset dxa (0..3): pixel column j + dxa, swizzled half
+  const int xrow0 = ((wave * PT) * XROW + j) * 32;
+  auto xl = [&](int dxa) { return xrow0 + dxa * 32 + ((h ^ (((j + dxa) >> 3) & 1)) * 16); };
+  const int xlane0 = xl(0), xlane1 = xl(1), xlane2 = xl(2);
+  const int wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);
 
   auto compute = [&](int buf, int dy0, int dx0) {
     if constexpr (S2) {
-      const char* xs = smem + buf * STAGE + xlane + (dy0 * XROW + dx0) * 32;
+      const char* xb = smem + buf * STAGE + dy0 * XROW * 32;
       const char* ws = smem + buf * STAGE + XBYTES + wlane + (dy0 * 3 + dx0) * COT * 1024;
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         bf16x8 bx[PT + 1], a[2][COT];
+        const int dxa = dx0 + dx;  // 0..2
+        const char* xs = xb + (dxa == 0 ? xlane0 : dxa == 1 ? xlane1 : xlane2);
 #pragma unroll
-        for (int r = 0; r < PT + 1; ++r) bx[r] = *(const bf16x8*)(xs + (r * XROW + dx) * 32);
+        for (int r = 0; r < PT + 1; ++r) bx[r] = *(const bf16x8*)(xs + r * XROW * 32);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -151,14 +164,15 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
       }
       return;
     }
-    const char* xs = smem + buf * STAGE + xlane;
+    const char* xb = smem + buf * STAGE;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       // the PT+2 tile rows of this column offset serve all three dy: 3*(PT+2) + 9*COT reads per chunk, not 9*(PT+COT)
       bf16x8 bx[PT + 2], a[3][COT];
+      const char* xs = xb + (dx == 0 ? xlane0 : dx == 1 ? xlane1 : xlane2);
 #pragma unroll
-      for (int r = 0; r < PT + 2; ++r) bx[r] = *(const bf16x8*)(xs + (r * XROW + dx) * 32);
+      for (int r = 0; r < PT + 2; ++r) bx[r] = *(const bf16x8*)(xs + r * XROW * 32);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll

@@ -128,7 +128,11 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
     }
     valid = valid && gy >= 0 && gy < p.vH;
     const int sy = ((gy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
-    xoff[r] = valid ? (img_off + (sy * p.in_w + sx) * 8 + half * 4) : -1;
+    // LDS bank swizzle (WT == 32): the two 16-byte halves of tile column c are stored swapped when bit 3 of c is set, so the
+    // 32 lanes of one half (32-byte stride) cover all 64 banks per ds_read_b128 lane group instead of every slot twice
+    // (PMC before: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); see conv_bf16.hip's header
+    const int hsw = WT == 32 ? (half ^ ((col >> 3) & 1)) : half;
+    xoff[r] = valid ? (img_off + (sy * p.in_w + sx) * 8 + hsw * 4) : -1;
   }
 
   auto stage = [&](int buf, int cb) {
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
         glds16(src, xs + u * 1024);
       }
     }
-    const float* wsrc = wg + (size_t)cb * (WBYTES / 4) + lane * 4;
+    const float* wsrc = wg + (size_t)cb * (WBYTES / 4) + (lane ^ ((lane >> 4) & 1)) * 4;  // unit (cout i, half) <- half ^ bit3(i)
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
       const int u = r * NW + wave;
@@ -159,11 +163,16 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  const int xlane = ((wave * PT * RPG + jr) * XROW + jc) * 32 + h * 16;  // byte offset of this lane's B operand, tap (0,0), group 0
-  const int wlane = j * 32 + h * 16;                         // byte offset of this lane's A operand, tap 0, cot 0
+  // byte offset of this lane's B operand at tap column dx (tap row 0, group 0): tile column jc + dx, swizzled half
+  const int xrow0 = ((wave * PT * RPG + jr) * XROW + jc) * 32;
+  int xlane[KS];
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx)
+    xlane[dx] = xrow0 + dx * 32 + ((WT == 32 ? (h ^ (((jc + dx) >> 3) & 1)) : h) * 16);
+  const int wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);  // byte offset of this lane's A operand, tap 0, cot 0
 
   auto compute = [&](int buf) {
-    const char* xs = smem + buf * STAGE + xlane;
+    const char* xb = smem + buf * STAGE;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
 #pragma unroll
         for (int c = 0; c < COT; ++c) a[c] = *(const f32x4*)(ws + (tap * COT + c) * 1024);
 #pragma unroll
-        for (int r = 0; r < PT; ++r) b[r] = *(const f32x4*)(xs + ((r * RPG + dy) * XROW + dx) * 32);
+        for (int r = 0; r < PT; ++r) b[r] = *(const f32x4*)(xb + xlane[dx] + (r * RPG + dy) * XROW * 32);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll

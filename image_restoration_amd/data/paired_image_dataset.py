@@ -33,7 +33,9 @@ class PairedImageDataset(ImageSource, Dataset):
         else:
             self.paths = data_util.paired_paths_from_folder(dirs, keys, self.filename_tmpl)
         self.training = opt['phase'] == 'train'
-        self.device_augment = bool(opt.get('device_augment', False)) and self.training
+        mode = opt.get('device_augment', False)
+        self.device_augment = bool(mode) and self.training
+        self.ship_whole_images = self.device_augment and mode == 'full'   # equally sized images: the crop runs on the device too
 
     def __len__(self):
         return len(self.paths)
@@ -57,6 +59,11 @@ class PairedImageDataset(ImageSource, Dataset):
         lq = self.decode(entry['lq_path'], 'lq', as_float=False)
         lq_patch = transforms.check_pair_geometry(gt.shape, lq.shape, gt_size, scale, entry['gt_path'])
         top, left = transforms.draw_window(lq.shape[0], lq.shape[1], lq_patch)
-        (gt,), (lq,) = transforms.cut_pair([gt], [lq], top, left, lq_patch, scale, gt_size)
         code = transforms.draw_symmetry(self.opt['use_flip'], self.opt['use_rot'])
-        return {'lq_u8': np.ascontiguousarray(lq), 'gt_u8': np.ascontiguousarray(gt), 'sym': np.int32(code)}
+        item = {'sym': np.int32(code)}
+        if self.ship_whole_images:
+            item['window'] = np.array([top, left], np.int32)
+        else:
+            (gt,), (lq,) = transforms.cut_pair([gt], [lq], top, left, lq_patch, scale, gt_size)
+        item.update(lq_u8=np.ascontiguousarray(lq), gt_u8=np.ascontiguousarray(gt))
+        return item

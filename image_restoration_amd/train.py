@@ -13,7 +13,7 @@ import time
 import torch
 from torch.utils.data import DataLoader
 
-from .data import CPUPrefetcher, CUDAPrefetcher, EnlargedSampler
+from .data import DeviceFeed, DevicePatchPipeline, EnlargedSampler, HostFeed, PrefetchDataLoader
 from .models import build_model
 from .utils.options import dict2str, parse_options
 from .utils.registry import DATASET_REGISTRY
@@ -30,8 +30,12 @@ def create_train_loader(opt):
     ratio = dataset_opt.get('dataset_enlarge_ratio', 1)
     sampler = EnlargedSampler(train_set, opt['world_size'], opt['rank'], ratio)
     batch = dataset_opt['batch_size_per_gpu']
-    loader = DataLoader(train_set, batch_size=batch, shuffle=False, sampler=sampler,
-                        num_workers=dataset_opt.get('num_worker_per_gpu', 0), drop_last=True, pin_memory=True)
+    common = dict(dataset=train_set, batch_size=batch, shuffle=False, sampler=sampler,
+                  num_workers=dataset_opt.get('num_worker_per_gpu', 0), drop_last=True, pin_memory=True)
+    if dataset_opt.get('prefetch_mode') == 'cpu':   # the reference's PrefetchDataLoader: collation runs ahead on a thread
+        loader = PrefetchDataLoader(num_prefetch_queue=dataset_opt.get('num_prefetch_queue', 1), **common)
+    else:
+        loader = DataLoader(**common)
     iters_per_epoch = math.ceil(len(train_set) * ratio / (batch * opt['world_size']))
     total_iters = int(opt['train']['total_iter'])
     return loader, sampler, math.ceil(total_iters / iters_per_epoch), total_iters
@@ -93,11 +97,15 @@ def train_pipeline(root_path, argv=None):
     warmup = opt['train'].get('warmup_iter', -1)
     t_iter = time.time()
     # datasets.train.prefetch_mode: None / 'cpu' iterate the loader, 'cuda' stages the next batch on a copy stream
-    prefetch_mode = next(v for v in opt['datasets'].values() if v['phase'] == 'train').get('prefetch_mode')
+    train_block = next(v for v in opt['datasets'].values() if v['phase'] == 'train')
+    prefetch_mode = train_block.get('prefetch_mode')
+    device_side = DevicePatchPipeline(train_block) if train_block.get('device_augment') else None
+    if device_side is not None and prefetch_mode != 'cuda':
+        raise ValueError("device_augment needs prefetch_mode: cuda (the augmentation kernel runs on the feed's copy stream)")
     if prefetch_mode is None or prefetch_mode == 'cpu':
-        prefetcher = CPUPrefetcher(loader)
+        prefetcher = HostFeed(loader)
     elif prefetch_mode == 'cuda':
-        prefetcher = CUDAPrefetcher(loader, opt)
+        prefetcher = DeviceFeed(loader, opt, pipeline=device_side)
     else:
         raise ValueError(f"Wrong prefetch_mode {prefetch_mode}. Supported ones are: None, 'cuda', 'cpu'.")
     for epoch in range(start_epoch, total_epochs + 1):

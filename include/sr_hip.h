@@ -219,6 +219,21 @@ int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float*
 /* out = a + b (skip connections of UNetDiscriminatorSN); n multiple of 4. */
 int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* Training input pipeline on the device: crop window + flip / transpose + uint8 -> float32 + channel swap +
+ * normalisation of a batch in one launch.  Replaces, per sample on the host: paired_random_crop and augment
+ * (basicsr/data/transforms.py:26-158), img2tensor (utils/img_util.py:9-35) on imfrombytes(float32=True) images (:128-132) and
+ * the mean / std normalisation of paired_image_dataset.py:94-96.
+ *   src  uint8 [n][src_h][src_w][3] HWC in decode order (BGR), images src_img_stride BYTES apart (0 = dense)
+ *   top, left  device int32[n], window origin (multiplied by origin_mul: LQ coordinates x scale address the GT tensor); both NULL = 0
+ *   sym  device int32[n]: bit0 horizontal flip, bit1 vertical flip, bit2 transpose, applied in that order (NULL = none);
+ *        a transposing batch needs patch_h == patch_w
+ *   dst  float32 [n][3][patch_h][patch_w] CHW; channel c = source channel (swap_rb ? 2-c : c);
+ *        value = (u8 / 255 - mean[c]) / std[c]  with IEEE division (bit-identical to the host pipeline); host_mean3 / host_std3
+ *        are HOST pointers to 3 floats or NULL. */
+int sr_patch_augment_u8_f32(const uint8_t* src, int64_t src_img_stride, int src_h, int src_w, const int32_t* top,
+                            const int32_t* left, int origin_mul, const int32_t* sym, float* dst, int n, int patch_h, int patch_w,
+                            int swap_rb, const float* host_mean3, const float* host_std3, void* stream);
+
 /* Validation PSNR numerator (psnr_ssim.py:8-46 on tensor2img outputs, img_util.py:38-94): per image n,
  * sse[n] = sum over channels and the border-cropped region of (round(clamp(a,0,1)*255) - round(clamp(b,0,1)*255))^2,
  * a, b NCHW float in [0,1].  ws >= n*64 floats. */

@@ -199,3 +199,57 @@ def test_path_pairing_matches_the_reference(golden, tmp_path):
     meta = tmp_path / 'meta.txt'
     meta.write_text('a9.png (480,480,3)\n0802.png (480,480,3)\n')
     assert rel(paired_paths_from_meta_info_file([str(lq_dir), str(gt_dir)], ['lq', 'gt'], str(meta), '{}x4')) == json.loads(str(g['meta']))
+
+
+def test_background_loader_runs_ahead_and_propagates_errors(folders):
+    """PrefetchDataLoader / BackgroundIterator (reference prefetch_dataloader.py:7-63): same batches in the same order as the plain
+    loader, produced on a daemon thread at most ``num_prefetch_queue`` ahead; a failure inside the producer surfaces in the consumer."""
+    from image_restoration_amd.data import BackgroundIterator, PrefetchDataLoader
+    gt_dir, lq_dir = folders
+    ds = PairedImageDataset(dict(name='t', type='PairedImageDataset', dataroot_gt=gt_dir, dataroot_lq=lq_dir, filename_tmpl='{}x4',
+                                 io_backend=dict(type='disk'), scale=4, phase='val'))
+    plain = [b['lq_path'] for b in torch.utils.data.DataLoader(ds, batch_size=1)]
+    ahead = [b['lq_path'] for b in PrefetchDataLoader(num_prefetch_queue=2, dataset=ds, batch_size=1)]
+    assert ahead == plain and len(ahead) == 3
+    assert list(BackgroundIterator(iter(range(7)), 3)) == list(range(7))
+
+    def broken():
+        yield 1
+        raise KeyError('decode failed')
+    it = BackgroundIterator(broken(), 2)
+    assert next(it) == 1
+    with pytest.raises(KeyError):
+        next(it)
+
+
+@pytest.mark.parametrize('mode', [True, 'full'])
+def test_device_augment_items_carry_the_same_draws_as_the_host_pipeline(tmp_path, mode):
+    """device_augment: the dataset consumes Python's random exactly like the host path (window, then symmetry), so after either
+    kind of item the generator is in the same state; the uint8 windows it ships are the host path's crops before any float work."""
+    gt_dir, lq_dir = tmp_path / 'gt', tmp_path / 'lq'
+    gt_dir.mkdir(), lq_dir.mkdir()
+    for i in range(3):
+        lq, gt = _coord_pair(20, 24, 4)
+        Image.fromarray(gt).save(gt_dir / f'im{i}.png')
+        Image.fromarray(lq).save(lq_dir / f'im{i}x4.png')
+    base = dict(name='t', type='PairedImageDataset', dataroot_gt=str(gt_dir), dataroot_lq=str(lq_dir), filename_tmpl='{}x4',
+                io_backend=dict(type='disk'), scale=4, phase='train', gt_size=32, use_flip=True, use_rot=True)
+    host, dev = PairedImageDataset(dict(base)), PairedImageDataset(dict(base, device_augment=mode))
+    for i in range(3):
+        random.seed(40 + i)
+        a = host[i]
+        after_host = random.random()
+        random.seed(40 + i)
+        b = dev[i]
+        assert random.random() == after_host
+        assert b['lq_u8'].dtype == np.uint8 and b['gt_u8'].dtype == np.uint8 and 0 <= int(b['sym']) < 8
+        if mode == 'full':
+            assert b['lq_u8'].shape == (20, 24, 3) and b['gt_u8'].shape == (80, 96, 3) and b['window'].shape == (2,)
+            t, l = (int(v) for v in b['window'])
+            lq_win = b['lq_u8'][t:t + 8, l:l + 8]
+        else:
+            assert b['lq_u8'].shape == (8, 8, 3) and b['gt_u8'].shape == (32, 32, 3) and 'window' not in b
+            lq_win = b['lq_u8']
+        from image_restoration_amd.data.transforms import apply_symmetry
+        want = apply_symmetry(lq_win, int(b['sym']))[:, :, ::-1].transpose(2, 0, 1).astype(np.float32) / 255.
+        assert np.array_equal(a['lq'].numpy(), want)
