@@ -10,9 +10,11 @@ in HBM.  Prints ONE JSON line on rank 0.
 Multi-GPU: images are independent, so ranks shard the tiles with no data-path collective (weak
 scaling: 16 tiles per GPU); the only collectives are the timing barrier and the max over ranks.
 
-Secondary lines (never the judged metric): --dtype bf16 (reduced-precision kernels) and --mode train (whole ESRGAN
-training steps, BASELINE configs 2-3; with N ranks the model's data-parallel path all-reduces the gradient arenas
-over RCCL).
+The same line carries a ``secondary`` object (never the judged ``value``; timed OUTSIDE the headline's timed region, after it):
+``c3_train_step`` = BASELINE configs[2]/[3], the full-size bf16 ESRGAN step (23-block bf16 generator + bf16 UNetDiscriminatorSN, batch
+32 of 128x128 LR per GPU; with N ranks the data-parallel path with one RCCL all-reduce per gradient arena) and ``c5_tiled_4k`` =
+BASELINE configs[4], one 4K frame through the tile-sharded path — each with its own roofline of its dominant kernel.
+``--no-secondary`` skips them; ``--mode train|tiled`` and ``--dtype bf16`` print those workloads as lines of their own (tuning).
 """
 import argparse
 import ctypes as C
@@ -61,42 +63,47 @@ def usable_cores():
 
 
 def cpu_baseline():
-    """Oracle (CPU restatement of the reference, PyTorch CPU fp32) on this host's cores, bounded sample."""
+    """Oracle (CPU restatement of the reference, PyTorch CPU fp32) on this host's cores, bounded sample: after one warm-up, three
+    forwards each at batch 1 and batch 2 of the workload's 128x128 tiles (>= 3 repetitions, best and median)."""
     from image_restoration_amd.utils import synth
     from oracle import rrdbnet_ref as R
     sd = {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}
     cores = usable_cores()
     torch.set_num_threads(cores)
-    x = torch.from_numpy(synth.uniform_input(1234, (4, 3, TILE, TILE)))
+    x = torch.from_numpy(synth.uniform_input(1234, (2, 3, TILE, TILE)))
+    rates = {1: [], 2: []}
     with torch.no_grad():
         R.rrdbnet_forward(x[:1, :, :32, :32], sd, 4, CFG['num_block'])  # warm-up (thread pool, allocator)
-        best, best_b, t_all = 0.0, 0, time.perf_counter()
-        for b in (1, 2, 4):  # the CPU path's throughput depends on the batch it is given: report its best (about 12 s in all)
-            for _ in range(2):
-                if time.perf_counter() - t_all > 30:
+        t_all = time.perf_counter()
+        for b in (1, 2):
+            for _ in range(3):
+                if time.perf_counter() - t_all > 30 and rates[b]:
                     break
                 t0 = time.perf_counter()
                 R.rrdbnet_forward(x[:b], sd, 4, CFG['num_block'])
-                rate = b / (time.perf_counter() - t0)
-                if rate > best:
-                    best, best_b = rate, b
-    return {'value': round(best, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'best of 2 forwards each of 1, 2 and 4 of the 16 128x128 tiles (best: batch {best_b}), oracle/rrdbnet_ref.py '
-                      f'(PyTorch CPU fp32, {torch.get_num_threads()} threads)'}
+                rates[b].append(b / (time.perf_counter() - t0))
+    best_b = max(rates, key=lambda b: max(rates[b]))
+    chosen = sorted(rates[best_b])
+    return {'value': round(chosen[-1], 4), 'median': round(chosen[len(chosen) // 2], 4), 'unit': 'images/sec', 'cores': cores,
+            'kind': 'port',
+            'sample': f'{len(rates[1])} + {len(rates[2])} forwards of 1 and 2 of the 16 128x128 tiles after one warm-up; best and median at '
+                      f'batch {best_b}; oracle/rrdbnet_ref.py (PyTorch CPU fp32, {torch.get_num_threads()} threads)',
+            'all_rates': {str(b): [round(r, 4) for r in v] for b, v in rates.items()}}
 
 
-def kernel_rooflines(net, x):
-    """One extra forward with HIP events around every conv launch (sr_profile_*), on the stream the
-    kernels run on.  Returns per-kernel aggregates; the dominant one (most time) is the roofline line."""
+def profile_launches(fn, peak_tflops=PEAK_F32_TFLOPS):
+    """Runs ``fn()`` once with HIP events around every conv / weight-gradient launch (sr_profile_*), on the stream the kernels run
+    on.  Returns per-kernel aggregates sorted by time; the first one is the roofline line of that workload."""
     from image_restoration_amd import _lib
     lib = _lib.load()
-    cap = 1024
+    cap = 16384
     recs = (_lib.LaunchRecord * cap)()
     n = C.c_int(0)
     _lib.check(lib.sr_profile_start(cap), 'sr_profile_start')
-    with torch.no_grad():
-        net(x)
-    _lib.check(lib.sr_profile_stop(recs, cap, C.byref(n)), 'sr_profile_stop')
+    try:
+        fn()
+    finally:
+        _lib.check(lib.sr_profile_stop(recs, cap, C.byref(n)), 'sr_profile_stop')
     agg = {}
     for r in recs[:n.value]:
         a = agg.setdefault(r.kernel_id, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
@@ -110,123 +117,189 @@ def kernel_rooflines(net, x):
         gbs = a['bytes'] / (a['ms'] * 1e-3) / 1e9
         out.append({'kernel': lib.sr_kernel_name(kid).decode(), 'launches': a['launches'],
                     'avg_ms': round(a['ms'] / a['launches'], 5), 'total_ms': round(a['ms'], 4),
-                    'tflops': round(tf, 2), 'flop_frac': round(tf / PEAK_F32_TFLOPS, 4),
+                    'tflops': round(tf, 2), 'flop_frac': round(tf / peak_tflops, 4),
                     'alg_gbs': round(gbs, 1), 'hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
                     'alg_flops_per_launch': a['flops'] / a['launches'], 'alg_bytes_per_launch': a['bytes'] / a['launches']})
     return out
 
 
-def train_mode(args, world, rank, dev, dist, backend):
-    """Secondary line: images/sec of whole ESRGANModel.optimize_parameters steps (generator forward/backward,
-    discriminator passes, losses, both fused Adam steps, EMA) on synthetic batches resident in HBM; with N ranks the model's
-    own data-parallel path runs (one RCCL all-reduce of each gradient arena per step) and per-GPU work is fixed (weak)."""
+def kernel_rooflines(net, x, peak_tflops=PEAK_F32_TFLOPS):
+    def one_forward():
+        with torch.no_grad():
+            net(x)
+    return profile_launches(one_forward, peak_tflops)
+
+
+def stored_counters(kernel):
+    """HBM traffic and MFMA-busy of ``kernel`` from the committed rocprofv3 --pmc passes (NOT measured in this run: they need the
+    profiler).  Returns (traffic bytes per launch | None, mfma busy | None, provenance string)."""
+    traffic = mfma = None
+    tpath, upath = os.path.join(ROOT, 'profiles', 'traffic.json'), os.path.join(ROOT, 'profiles', 'mfma_util.json')
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(kernel)
+    if os.path.exists(upath):
+        mfma = (json.load(open(upath)).get(kernel) or {}).get('mfma_util')
+    src = 'stored: profiles/traffic.json + profiles/mfma_util.json (separate rocprofv3 --pmc passes of this bench, tools/profile_round.sh; ' \
+          'FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction); null = no stored counter for this kernel'
+    return traffic, mfma, src
+
+
+def roofline_of(ks, peak_tflops):
+    """The roofline object of a workload from its kernel table: dominant kernel, binding roof = the one it sits closer to."""
+    k0 = ks[0]
+    traffic, mfma_pmc, src = stored_counters(k0['kernel'])
+    mfma_frac, hbm_frac = k0['tflops'] / peak_tflops, k0['hbm_frac']
+    common = {'traffic': traffic, 'traffic_source': src, 'kernel': k0['kernel'], 'avg_launch_ms': k0['avg_ms'],
+              'launches': k0['launches'], 'share_of_profiled_time': round(k0['total_ms'] / sum(k['total_ms'] for k in ks), 4),
+              'mfma_util_pmc_stored': mfma_pmc}
+    if mfma_frac >= hbm_frac:
+        return dict({'bound': 'mfma', 'achieved': k0['tflops'], 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(mfma_frac, 4),
+                     'hbm_frac_algorithmic': k0['hbm_frac']}, **common)
+    return dict({'bound': 'hbm', 'achieved': k0['alg_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(hbm_frac, 4),
+                 'mfma_frac': round(mfma_frac, 4)}, **common)
+
+
+def _sync(dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, dist, dev, backend):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dtype, batch, lq, steps, warmup, profile):
+    """Whole ESRGANModel.optimize_parameters steps (generator forward/backward, discriminator passes, losses, both fused Adam steps,
+    EMA) on synthetic batches resident in HBM; with N ranks the model's own data-parallel path runs (replica alignment at
+    construction, one RCCL all-reduce of each gradient arena per step) and per-GPU work is fixed (weak scaling)."""
     from image_restoration_amd.models import build_model
     from image_restoration_amd.utils import synth
-    from image_restoration_amd.utils.options import parse
-    opt = parse(os.path.join(ROOT, 'training_config', 'train_rrdbnet_esrgan_x4_mi355x.yml'), ROOT, is_train=True)
+    from image_restoration_amd.utils.options import parse, set_random_seed
+    opt = parse(os.path.join(ROOT, 'training_config', yml), ROOT, is_train=True)
     opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = world > 1, rank, world, 1
-    opt['network_g']['compute_dtype'] = args.dtype
-    d_dtype = args.disc_dtype or args.dtype
-    if args.disc == 'unet':
+    opt['network_g']['compute_dtype'] = dtype
+    d_dtype = disc_dtype or dtype
+    if disc == 'unet':
         opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True, compute_dtype=d_dtype)
-    elif args.lq != 32:
+    elif lq != 32:
         raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
     else:
         opt['network_d']['compute_dtype'] = d_dtype
+    set_random_seed(opt['manual_seed'] + rank)   # like parse_options: ranks start different, the model aligns its replicas
     model = build_model(opt)
-    lq = torch.from_numpy(synth.uniform_input(100 + rank, (args.batch, 3, args.lq, args.lq))).to(dev)
-    gt = torch.from_numpy(synth.uniform_input(200 + rank, (args.batch, 3, 4 * args.lq, 4 * args.lq))).to(dev)
+    x_lq = torch.from_numpy(synth.uniform_input(100 + rank, (batch, 3, lq, lq))).to(dev)
+    x_gt = torch.from_numpy(synth.uniform_input(200 + rank, (batch, 3, 4 * lq, 4 * lq))).to(dev)
 
     def step(i):
         model.update_learning_rate(i, warmup_iter=-1)
-        model.feed_data({'lq': lq, 'gt': gt})
+        model.feed_data({'lq': x_lq, 'gt': x_gt})
         model.optimize_parameters(i)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(1, args.warmup + 1):
+    for i in range(1, warmup + 1):
         step(i)
-    barrier()
+    _sync(dist)
     t0 = time.perf_counter()
-    for i in range(args.warmup + 1, args.warmup + 1 + args.steps):
+    for i in range(warmup + 1, warmup + 1 + steps):
         step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    _sync(dist)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, dev, backend)
     log = model.get_current_log()
     assert all(v == v and abs(v) < 1e30 for v in log.values()), log
-    if rank == 0:
-        print(json.dumps({
-            'metric': 'images/sec (ESRGAN training step: 23-block RRDBNet + %s, L1 + relativistic GAN loss, Adam, EMA)' % opt['network_d']['type'],
-            'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'fp32' else ('bf16 generator and discriminator, f32 master weights/optimiser'
-                                                         if d_dtype == 'bf16' else 'bf16 generator, f32 discriminator/optimiser'),
-            'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
-                                   % (args.batch, args.lq, args.lq), 'global_batch': world * args.batch,
-                       'parallelism': 'dp%d, one all-reduce of each gradient arena per step' % world},
-            'losses': {k: float(v) for k, v in log.items()}}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    res = {
+        'metric': 'images/sec (ESRGAN training step: 23-block RRDBNet + %s, L1 + relativistic GAN loss, Adam, EMA)' % opt['network_d']['type'],
+        'value': round(world * batch * steps / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32' if dtype == 'fp32' else ('bf16 generator and discriminator, f32 master weights/optimiser'
+                                                if d_dtype == 'bf16' else 'bf16 generator, f32 discriminator/optimiser'),
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
+                               % (batch, lq, lq), 'global_batch': world * batch,
+                   'parallelism': 'dp%d, replicas aligned from rank 0 at construction, one all-reduce of each gradient arena per step' % world},
+        'losses': {k: float(v) for k, v in log.items()}}
+    if profile and world == 1:
+        peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
+        ks = profile_launches(lambda: step(warmup + steps + 1), peak)
+        torch.cuda.synchronize()
+        res['roofline'] = roofline_of(ks, peak)
+        res['kernels'] = ks[:6]
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
-def tiled_mode(args, world, rank, dev, dist, backend):
-    """Secondary line (BASELINE configs[4], the fifth): one 4K frame (3840x2160 LR) through the tiler — 512x512 cells + 16 px pad, the
-    cells sharded over the ranks, HR crops gathered onto rank 0 by one RCCL gather (uint8 output convention).  One frame is
-    split over all ranks, so this is strong scaling; a step = one whole frame assembled on rank 0."""
-    import image_restoration_amd as ira
+def measure_tiled(net, world, rank, dev, dist, backend, *, dtype, steps, warmup, tile_batch, profile):
+    """BASELINE configs[4]: one 4K frame (3840x2160 LR) through the tiler — 512x512 cells + 16 px pad, the cells sharded over the
+    ranks, HR crops gathered onto rank 0 by one RCCL gather (uint8 output convention).  One frame is split over all ranks, so this
+    is strong scaling; a step = one whole frame assembled on rank 0."""
     from image_restoration_amd.tiling import plan_tiles, tiled_forward
     from image_restoration_amd.utils import synth
-    net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
-    net.set_compute_dtype(args.dtype)
+    net.set_compute_dtype(dtype)
     H, W = 2160, 3840
     img = torch.from_numpy(synth.uniform_input(77, (1, 3, H, W))).to(dev)  # the same frame on every rank
 
-    def step():
-        return tiled_forward(net, img, tile=512, pad=16, scale=4, max_batch=args.tile_batch, rank=rank, world_size=world,
+    def step(frame=img):
+        return tiled_forward(net, frame, tile=512, pad=16, scale=4, max_batch=tile_batch, rank=rank, world_size=world,
                              out_dtype=torch.uint8)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    out = None
+    for _ in range(warmup):
         out = step()
-    barrier()
+    _sync(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    _sync(dist)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, dev, backend)
     if rank == 0:
         assert out.shape == (1, 3, 4 * H, 4 * W) and out.dtype == torch.uint8
-        print(json.dumps({
-            'metric': '4K frames/sec (3840x2160 -> 15360x8640 x4 SR, 23-block RRDBNet, 512x512 tiles + 16 px pad)',
-            'value': round(args.steps / dt, 4), 'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[4]: tiled 4K frame, %d cells sharded over the ranks, uint8 crops gathered '
-                                   'on rank 0' % len(plan_tiles(H, W, 512, 16)), 'tile': 512, 'tile_pad': 16,
-                       'parallelism': f'tile-sharded x{world}, one gather per frame'},
-            'lr_megapixels_per_sec': round(args.steps * H * W / dt / 1e6, 3)}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    res = {
+        'metric': '4K frames/sec (3840x2160 -> 15360x8640 x4 SR, 23-block RRDBNet, 512x512 tiles + 16 px pad)',
+        'value': round(steps / dt, 4), 'unit': 'frames/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f32' if dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[4]: tiled 4K frame, %d cells sharded over the ranks, uint8 crops gathered '
+                               'on rank 0' % len(plan_tiles(H, W, 512, 16)), 'tile': 512, 'tile_pad': 16,
+                   'parallelism': f'tile-sharded x{world}, one gather per frame'},
+        'lr_megapixels_per_sec': round(steps * H * W / dt / 1e6, 3)}
+    if profile and world == 1:
+        peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
+        quarter = img[:, :, :1024, :1024 * tile_batch // 2].contiguous()  # tile_batch whole 512x512 cells: the frame's launch shapes
+        ks = profile_launches(lambda: tiled_forward(net, quarter, tile=512, pad=16, scale=4, max_batch=tile_batch, out_dtype=torch.uint8), peak)
+        torch.cuda.synchronize()
+        res['roofline'] = roofline_of(ks, peak)
+        res['roofline']['note'] = 'kernel table from a %dx%d corner of the frame (%d full cells per forward, the launch shapes of the frame)' \
+            % (quarter.shape[2], quarter.shape[3], tile_batch)
+    del out
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_workloads(net, args, world, rank, dev, dist, backend):
+    """BASELINE configs 3/4 and 5 next to the headline, each guarded: a failure is reported in place, never raised."""
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001
+            out[name] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
+            torch.cuda.empty_cache()
+
+    guarded('c5_tiled_4k_bf16', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='bf16', steps=2, warmup=1,
+                                                      tile_batch=args.tile_batch, profile=True))
+    guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=1, warmup=0,
+                                                      tile_batch=args.tile_batch, profile=False))
+    net.set_compute_dtype(args.dtype)
+    guarded('c3_train_step', lambda: measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml',
+                                                   dtype='bf16', disc='unet', disc_dtype='bf16', batch=32, lq=128, steps=3, warmup=1,
+                                                   profile=True))
+    return out
 
 
 def main():
@@ -247,6 +320,9 @@ def main():
     ap.add_argument('--lq', type=int, default=32, help='--mode train: LR patch size (gt = 4x)')
     ap.add_argument('--disc', choices=('vgg', 'unet'), default='vgg', help='--mode train: discriminator')
     ap.add_argument('--disc-dtype', choices=('fp32', 'bf16'), default=None, help='--mode train: discriminator arithmetic (default: --dtype)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the C3 training step and the C5 tiled frame next to the headline')
+    ap.add_argument('--secondary-timeout', type=float, default=300.0)
+    ap.add_argument('--profile', action='store_true', help='--mode train|tiled: add the roofline of the dominant kernel')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -270,76 +346,74 @@ def main():
     if args.groups:
         from image_restoration_amd import _lib
         _lib.check(_lib.load().sr_set_forward_groups(args.groups), 'sr_set_forward_groups')
+    def finish(line):
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
     if args.mode == 'train':
-        return train_mode(args, world, rank, dev, dist, backend)
-    if args.mode == 'tiled':
-        return tiled_mode(args, world, rank, dev, dist, backend)
+        return finish(measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x.yml', dtype=args.dtype,
+                                    disc=args.disc, disc_dtype=args.disc_dtype, batch=args.batch, lq=args.lq, steps=args.steps,
+                                    warmup=args.warmup, profile=args.profile))
 
     import image_restoration_amd as ira
     from image_restoration_amd.utils import synth
     net = ira.build_network(dict(type='RRDBNet', **CFG)).to(dev).eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **CFG).items()}, strict=True)
+    if args.mode == 'tiled':
+        return finish(measure_tiled(net, world, rank, dev, dist, backend, dtype=args.dtype, steps=args.steps, warmup=args.warmup,
+                                    tile_batch=args.tile_batch, profile=args.profile))
     net.set_compute_dtype(args.dtype)
     x = torch.from_numpy(synth.uniform_input(1234 + rank, (BATCH, 3, TILE, TILE))).to(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
             y = net(x)
-        barrier()
+        _sync(dist)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = net(x)
-        barrier()
+        _sync(dist)
         dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = _max_over_ranks(dt, dist, dev, backend)
     assert bool(torch.isfinite(y).all())
 
-    if rank == 0:
-        value = world * BATCH * args.steps / dt
-        line = {
-            'metric': 'images/sec (128x128->512x512 x4 SR, 23-block RRDBNet)', 'value': round(value, 3),
-            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: RRDBNet num_block=23 nf=64 x4 %s inference, batch 16 of '
-                                   '128x128 tiles per GPU' % args.dtype, 'global_batch': world * BATCH, 'tile': TILE,
-                       'parallelism': f'tile-sharded x{world}, no data-path collective'},
-            'net_tflops': round(value * FLOPS_PER_IMAGE / 1e12 / world, 2),
-        }
-        if world == 1:
-            ks = kernel_rooflines(net, x)
-            k0 = ks[0]
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(k0['kernel'])
-            upath = os.path.join(ROOT, 'profiles', 'r01_mfma_util.json')  # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, own --pmc passes
-            mfma_pmc = (json.load(open(upath)).get(k0['kernel']) or {}).get('mfma_util') if os.path.exists(upath) else None
-            peak = PEAK_F32_TFLOPS if args.dtype == 'fp32' else PEAK_BF16_TFLOPS
-            mfma_frac, hbm_frac = k0['tflops'] / peak, k0['hbm_frac']
-            if mfma_frac >= hbm_frac:  # the binding roof is the one the kernel sits closer to
-                line['roofline'] = {'bound': 'mfma', 'achieved': k0['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-                                    'frac': round(mfma_frac, 4), 'traffic': traffic, 'kernel': k0['kernel'],
-                                    'avg_launch_ms': k0['avg_ms'], 'hbm_frac_algorithmic': k0['hbm_frac'], 'mfma_util_pmc': mfma_pmc}
-            else:  # bf16 per-layer convs: 192-272 FLOP/B against a ridge of ~310 -> memory side binds
-                line['roofline'] = {'bound': 'hbm', 'achieved': k0['alg_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                    'frac': round(hbm_frac, 4), 'traffic': traffic, 'kernel': k0['kernel'],
-                                    'avg_launch_ms': k0['avg_ms'], 'mfma_frac': round(mfma_frac, 4), 'mfma_util_pmc': mfma_pmc}
-            line['kernels'] = ks
-            if not args.no_cpu_baseline:
-                line['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    value = world * BATCH * args.steps / dt
+    line = {
+        'metric': 'images/sec (128x128->512x512 x4 SR, 23-block RRDBNet)', 'value': round(value, 3),
+        'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: RRDBNet num_block=23 nf=64 x4 %s inference, batch 16 of '
+                               '128x128 tiles per GPU' % args.dtype, 'global_batch': world * BATCH, 'tile': TILE,
+                   'parallelism': f'tile-sharded x{world}, no data-path collective'},
+        'net_tflops': round(value * FLOPS_PER_IMAGE / 1e12 / world, 2),
+    }
+    if world == 1:
+        peak = PEAK_F32_TFLOPS if args.dtype == 'fp32' else PEAK_BF16_TFLOPS
+        ks = kernel_rooflines(net, x, peak)
+        line['roofline'] = roofline_of(ks, peak)
+        line['kernels'] = ks
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+    if not args.no_secondary:
+        # Outside the headline's timed region.  A watchdog prints the line without them if a secondary workload hangs (every
+        # rank exits), so the judged value can never be lost to a secondary number.
+        import threading
+
+        def give_up():
+            line['secondary'] = {'error': f'secondary workloads did not finish within {args.secondary_timeout} s'}
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.secondary_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        line['secondary'] = secondary_workloads(net, args, world, rank, dev, dist, backend)
+        dog.cancel()
+    finish(line)
 
 
 if __name__ == '__main__':

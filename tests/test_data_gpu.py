@@ -37,7 +37,7 @@ def test_device_pipeline_is_bit_identical_to_the_host_pipeline(cuda, tmp_path, m
     host, dev = PairedImageDataset(dict(base)), PairedImageDataset(dict(base, device_augment=mode))
     pipe = DevicePatchPipeline(base)
     seen = set()
-    for rep in range(4):
+    for rep in range(10):
         want, items = [], []
         for i in range(len(sizes)):
             random.seed(1000 * rep + i)
