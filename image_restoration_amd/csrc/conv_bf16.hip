@@ -62,9 +62,20 @@ __device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
 // (ry, rx) of channels has non-zero weights on 2x2 of the 9 taps only — rows {1-ry, 2-ry}, columns {1-rx, 2-rx} of the
 // forward image (input-channel parity), rows {ry, ry+1}, columns {rx, rx+1} of the data-gradient image (output-channel
 // parity) — and the loop issues those 4 taps (4/9 of the LDS reads and MFMAs; the skipped products are exact zeros).
-template <int COT, int PT, int NW, bool NCHW_OUT, bool S2 = false>
-__global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// 16-byte store that writes through to memory (sc1): how a tile that another workgroup of the SAME launch will read is published
+// (MI355X_MICROARCH.md, inter-workgroup visibility: write-through stores + every wave's vmcnt(0) + barrier + flag; no L2 write-back).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(void* ptr, u32x4_t v, bool write_through) {
+  if (write_through)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory");
+  else
+    *(u32x4_t*)ptr = v;
+}
+
+// One output tile (TH rows x 32 columns x 32*COT couts) of one conv: the whole body of conv_bf16_kernel, also run once per work
+// item by the persistent chain kernel below.  WT_OUT: publish the tile with write-through stores.
+template <int COT, int PT, int NW, bool NCHW_OUT, bool S2, bool WT_OUT>
+__device__ __forceinline__ void conv_tile_h(const ConvParamsH& p, const int cog, const int tx, const int ty, const int n, char* smem) {
   constexpr int TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
   constexpr int NXU = XBYTES / 1024, NWU = 9 * COT;
@@ -74,22 +85,6 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous run of the
-  // (tile, cout group) sequence with the cout group fastest: the cout groups of one pixel tile run side by side on one
-  // XCD and share the tile's input through that XCD's L2 (a deep layer with 4-8 cout groups otherwise re-reads its whole
-  // input from HBM once per group), and neighbouring tiles share halo rows and weights.
-  int t;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  const int cog = t % p.cogs;
-  t /= p.cogs;
-  const int tx = t % p.tiles_x;
-  t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int n = t / p.tiles_y;
   const int x0 = tx * 32, y0 = ty * TH;
   const long long plane_b = (long long)p.in_h * p.in_w * 32;  // bytes of one 16-channel block plane
   const char* in_n = p.in + (long long)n * p.in_nb;
@@ -296,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
           }
           u32x4 o = {f2bf2(v[0][0], v[0][1]), f2bf2(v[0][2], v[0][3]), f2bf2(v[1][0], v[1][1]), f2bf2(v[1][2], v[1][3])};
           swap_halves(o);
-          *(u32x4*)(p.out + (long long)n * p.out_nb + off) = o;
+          store16(p.out + (long long)n * p.out_nb + off, o, WT_OUT);
         }
       }
     }
@@ -306,6 +301,113 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
     long long* o = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
     o[0] = tk[0]; o[1] = tk[1] - tk[0]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tk[4] - tk[0]; o[5] = tk[5] - tk[4];
     o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+}
+
+template <int COT, int PT, int NW, bool NCHW_OUT, bool S2 = false>
+__global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous run of the
+  // (tile, cout group) sequence with the cout group fastest: the cout groups of one pixel tile run side by side on one
+  // XCD and share the tile's input through that XCD's L2 (a deep layer with 4-8 cout groups otherwise re-reads its whole
+  // input from HBM once per group), and neighbouring tiles share halo rows and weights.
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int cog = t % p.cogs;
+  t /= p.cogs;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  conv_tile_h<COT, PT, NW, NCHW_OUT, S2, false>(p, cog, tx, ty, n, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ persistent conv chain
+// The five convs of a residual dense block (rrdbnet_arch.py:32-39) — any chain in which conv k reads what convs < k wrote over the
+// same pixel grid — as ONE launch.  Work items (conv k, tile t) are claimed from a global counter in k-major order, so every
+// dependency of a claimed item (conv k-1 on t and its 8 neighbour tiles: the 1-pixel halo) was claimed earlier, i.e. is running on
+// a resident workgroup or finished: progress never depends on how many workgroups are resident (no co-residency assumption, no
+// grid barrier), and conv k+1 starts on the first tiles while conv k still runs on the last ones — ramp-up, tail and the kernel
+// boundary are paid once per chain instead of once per conv.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): the producer stores its tile write-through (sc1), every wave drains
+// its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane stores done[tile] = epoch + convs finished with an
+// agent-scope relaxed store; the consumer's nine lanes poll the neighbours' words with agent-scope relaxed loads, then ONE
+// agent-scope acquire (buffer_inv sc1) + s_waitcnt vmcnt(0) + barrier, then plain loads / LDS-DMA.  Every spin is bounded: a
+// consumer that waits too long raises the chain's abort word and every workgroup leaves (the host entry point reports it).
+#define SR_CHAIN_MAX 5
+struct ChainParams {
+  ConvParamsH lv[SR_CHAIN_MAX];
+  int cot[SR_CHAIN_MAX];  // cout tile (1: 32 couts, 2: 64) per conv
+  int nconv, ntiles, tiles_x, tiles_y;
+  int* head;   // work counter of this launch (zero before the launch)
+  int* done;   // [ntiles] epoch + number of convs finished on the tile (monotone over the launches that share it)
+  int* abort;  // raised on a timed-out wait
+  int epoch;
+};
+
+__device__ __forceinline__ int flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int PT, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_chain_bf16_kernel(const ChainParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_item;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nitems = P.nconv * P.ntiles;
+  for (;;) {
+    if (wave == 0) {
+      int item = 0;
+      if (lane == 0) item = atomicAdd(P.head, 1);
+      item = __builtin_amdgcn_readfirstlane(item);
+      if (item < nitems && item >= P.ntiles) {  // conv k > 0: wait for conv k-1 on the 3x3 tile neighbourhood
+        const int k = item / P.ntiles;
+        int t = item - k * P.ntiles;
+        const int tx = t % P.tiles_x;
+        t /= P.tiles_x;
+        const int ty = t % P.tiles_y, n = t / P.tiles_y;
+        bool gave_up = false;
+        if (lane < 9) {
+          const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+          if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) {
+            const int* f = P.done + (n * P.tiles_y + ny) * P.tiles_x + nx;
+            const int want = P.epoch + k;
+            int spins = 0;
+            while (flag_load(f) < want) {
+              __builtin_amdgcn_s_sleep(2);
+              if ((++spins & 255) == 0 && (spins > (1 << 22) || flag_load(P.abort))) {
+                __hip_atomic_store(P.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+              }
+            }
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(gave_up)) item = nitems;  // any lane that gave up takes the whole workgroup out
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (lane == 0) s_item = item;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nitems) break;
+    const int k = item / P.ntiles;
+    int t = item - k * P.ntiles;
+    const int tile = t;
+    const int tx = t % P.tiles_x;
+    t /= P.tiles_x;
+    const int ty = t % P.tiles_y, n = t / P.tiles_y;
+    if (P.cot[k] == 2)
+      conv_tile_h<2, PT, NW, false, false, true>(P.lv[k], 0, tx, ty, n, smem);
+    else
+      conv_tile_h<1, PT, NW, false, false, true>(P.lv[k], 0, tx, ty, n, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
+    __syncthreads();                                   // ... and every other wave's; s_item may be rewritten
+    if (tid == 0) __hip_atomic_store(P.done + tile, P.epoch + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -352,23 +454,20 @@ long long* g_phase_clocks = nullptr;
 // launches writes its prologue / compute / barrier-wait / epilogue cycle counts to buf[(workgroup*NW + wave)*8 ..].
 extern "C" void sr_dev_conv_bf16_phase_clocks(void* buf) { g_phase_clocks = (long long*)buf; }
 
-// d->in / out / res*: CB16 bf16 tensors (out: NCHW fp32 when out_nchw); *_img_stride in ELEMENTS of the tensor's dtype;
-// cin_pad multiple of 16; wpacked from sr_conv3x3_pack_bf16 (passed through the float* field); bpacked fp32.
-extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SR_CHECK_ARG(d && d->in && d->wpacked && d->out, "sr_conv3x3_bf16: null argument");
-  SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 16 == 0, "sr_conv3x3_bf16: cin_pad=%d must be a multiple of 16", d->cin_pad);
-  SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_bf16: bad shape");
+static int fill_params_h(const sr_conv3x3_desc* d, ConvParamsH& p, const char* who) {
+  SR_CHECK_ARG(d && d->in && d->wpacked && d->out, "%s: null argument", who);
+  SR_CHECK_ARG(d->cin_pad > 0 && d->cin_pad % 16 == 0, "%s: cin_pad=%d must be a multiple of 16", who, d->cin_pad);
+  SR_CHECK_ARG(d->cout > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "%s: bad shape", who);
   SR_CHECK_ARG(!d->accumulate && d->res_cbn == 0 && d->mask_cb0 == 0 && !(d->mask_src && d->out_nchw),
-               "sr_conv3x3_bf16: accumulate / res_cbn / mask_cb0 are fp32-path options");
+               "%s: accumulate / res_cbn / mask_cb0 are fp32-path options", who);
   SR_CHECK_ARG(((uintptr_t)d->in | (uintptr_t)d->wpacked | (uintptr_t)d->out | (uintptr_t)d->res1 | (uintptr_t)d->res2 |
                 (uintptr_t)d->bpacked | (uintptr_t)d->mask_src) % 16 == 0,
-               "sr_conv3x3_bf16: pointers must be 16-byte aligned");
+               "%s: pointers must be 16-byte aligned", who);
   SR_CHECK_ARG(d->s2_channels == 0 || (d->s2_channels > 0 && d->s2_channels % 64 == 0 && !d->upsample &&
                                        (d->s2_side ? d->cout : d->cin_pad) == 4 * d->s2_channels),
-               "sr_conv3x3_bf16: s2_channels=%d must be a multiple of 64 and a quarter of the %s channels", d->s2_channels,
+               "%s: s2_channels=%d must be a multiple of 64 and a quarter of the %s channels", who, d->s2_channels,
                d->s2_side ? "output" : "input");
-  ConvParamsH p = {};
+  p = ConvParamsH{};
   p.zero = sr::zero_line();
   p.in = (const char*)d->in;
   p.w = (const char*)d->wpacked;
@@ -396,9 +495,90 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   p.alpha = d->alpha;
   p.beta1 = d->beta1;
   p.beta2 = d->beta2;
-  p.dbg = g_phase_clocks;
+  p.dbg = nullptr;
   SR_CHECK_ARG((long long)p.H * p.W * 32 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) < (1ll << 31),
-               "sr_conv3x3_bf16: image too large for 32-bit plane offsets");
+               "%s: image too large for 32-bit plane offsets", who);
+  return SR_OK;
+}
+
+// Ints of the `sync` block of sr_conv3x3_chain_bf16 for images of h x w pixels: [0] abort word, [1 .. 1+SR_CHAIN_EPOCHS) the work
+// counters of the calls that share the block, then one progress word per 16x32 tile.
+#define SR_CHAIN_EPOCHS 256
+extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  return 1 + SR_CHAIN_EPOCHS + (size_t)n * sr::cdiv(h, 16) * sr::cdiv(w, 32);
+}
+
+static bool g_chain_enabled = true;
+extern "C" int sr_set_conv_chain(int enabled) {
+  g_chain_enabled = enabled != 0;
+  return SR_OK;
+}
+
+extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
+  // eligibility of the one-launch form: one tile grid (same n, H, W, no upsampling), CB16 outputs, <= 64 couts, 16-row tiles,
+  // enough tiles to fill the chip; anything else runs conv by conv (same results)
+  bool one_launch = g_chain_enabled && sync && nconv >= 2 && nconv <= SR_CHAIN_MAX && call_index >= 0 && call_index < SR_CHAIN_EPOCHS &&
+                    !sr::prof_on();
+  for (int k = 0; k < nconv && one_launch; ++k) {
+    const sr_conv3x3_desc& c = d[k];
+    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 &&
+                 c.cout <= 64 && c.cin_pad <= 256 && !c.mask_src && c.in_h % 16 == 0;
+  }
+  const int conc = sr::launch_concurrency();
+  if (one_launch) one_launch = (long long)sr::cdiv(d[0].in_w, 32) * (d[0].in_h / 16) * d[0].n * conc >= 256;
+  if (!one_launch) {
+    for (int k = 0; k < nconv; ++k)
+      if (int rc = sr_conv3x3_bf16(&d[k], stream_)) return rc;
+    return SR_OK;
+  }
+  ChainParams P = {};
+  for (int k = 0; k < nconv; ++k) {
+    if (int rc = fill_params_h(&d[k], P.lv[k], "sr_conv3x3_chain_bf16")) return rc;
+    P.cot[k] = ((d[k].cout + 31) / 32 * 32) % 64 == 0 ? 2 : 1;
+    P.lv[k].tiles_x = sr::cdiv(P.lv[k].W, 32);
+    P.lv[k].tiles_y = P.lv[k].H / 16;
+    P.lv[k].cogs = 1;
+  }
+  P.nconv = nconv;
+  P.tiles_x = P.lv[0].tiles_x;
+  P.tiles_y = P.lv[0].tiles_y;
+  P.ntiles = P.tiles_x * P.tiles_y * d[0].n;
+  P.abort = sync;
+  P.head = sync + 1 + call_index;
+  P.done = sync + 1 + SR_CHAIN_EPOCHS;
+  P.epoch = call_index * 8;
+  constexpr int lds = conv_bf16_lds<2, 2, 8>();
+  auto kern = conv_chain_bf16_kernel<2, 8>;
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;
+  // Grid = what the chip holds at once (two workgroups per CU by LDS), shared between concurrently launching image groups.  Not a
+  // correctness condition (work items are claimed, see the kernel): more would only queue, fewer would idle CUs.
+  static int slots[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (slots[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    slots[dev] = (per_cu > 2 ? 2 : per_cu) * cus;
+  }
+  long long grid = slots[dev] / (conc > 1 ? conc : 1);
+  if (grid > P.ntiles) grid = P.ntiles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, P);
+  SR_CHECK_LAUNCH("conv_chain_bf16 launch");
+  return SR_OK;
+}
+
+// d->in / out / res*: CB16 bf16 tensors (out: NCHW fp32 when out_nchw); *_img_stride in ELEMENTS of the tensor's dtype;
+// cin_pad multiple of 16; wpacked from sr_conv3x3_pack_bf16 (passed through the float* field); bpacked fp32.
+extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvParamsH p;
+  if (int rc = fill_params_h(d, p, "sr_conv3x3_bf16")) return rc;
+  p.dbg = g_phase_clocks;
   const int cp = (d->cout + 31) / 32 * 32;
   const int gc = (cp % 64 == 0) ? 64 : 32;
   const int groups = cp / gc;

@@ -383,11 +383,8 @@ class PackedConvBF16:
                        'sr_conv3x3_pack_bf16')
 
 
-def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-                 beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0):
-    """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16.
-    s2_channels = C marks a 4x4/s2 conv carried on a pixel-unshuffled operand of 4C channels (zero taps are skipped)."""
-    lib = _lib.load()
+def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
+                    beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0):
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
     H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
     d = _lib.ConvDesc()
@@ -412,9 +409,36 @@ def conv3x3_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0,
         d.res2, d.res2_img_stride, d.beta2 = res2.ptr, res2.img_stride, beta2
     if mask is not None:
         d.mask_src, d.mask_img_stride, d.mask_cb0, d.mask_cbn, d.mask_slope = mask.ptr, mask.img_stride, 0, mask.cbn, mask_slope
+    return d, ret
+
+
+def conv3x3_bf16(src, pc, out=None, **kw):
+    """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16.
+    Keywords: upsample, act_slope, alpha, res1/beta1, res2/beta2, out_nchw, mask/mask_slope, s2_channels/s2_side
+    (s2_channels = C marks a 4x4/s2 conv carried on a pixel-unshuffled operand of 4C channels: zero taps are skipped)."""
+    lib = _lib.load()
+    d, ret = _conv_desc_bf16(src, pc, out, **kw)
     with torch.cuda.device(src.device):
         _lib.check(lib.sr_conv3x3_bf16(C.byref(d), _stream(src.device)), 'sr_conv3x3_bf16')
     return ret
+
+
+def conv3x3_chain_bf16(steps, sync=None, call_index=0):
+    """A dependency chain of convs as one persistent launch — sr_conv3x3_chain_bf16.  ``steps`` = [(src, pc, out, kwargs), ...] in
+    execution order (conv k reads what earlier convs wrote); ``sync`` = int32 tensor of sr_conv3x3_chain_sync_ints(n, h, w) zeros
+    (created when None).  Returns (outputs, sync); sync[0] != 0 after a synchronisation means a dependency wait timed out."""
+    lib = _lib.load()
+    src0 = steps[0][0]
+    if sync is None:
+        sync = torch.zeros(lib.sr_conv3x3_chain_sync_ints(src0.n, src0.h, src0.w), dtype=torch.int32, device=src0.device)
+    descs = (_lib.ConvDesc * len(steps))()
+    outs = []
+    for i, (src, pc, out, kw) in enumerate(steps):
+        descs[i], ret = _conv_desc_bf16(src, pc, out, **kw)
+        outs.append(ret)
+    with torch.cuda.device(src0.device):
+        _lib.check(lib.sr_conv3x3_chain_bf16(descs, len(steps), sync.data_ptr(), call_index, _stream(src0.device)), 'sr_conv3x3_chain_bf16')
+    return outs, sync
 
 
 def conv3x3_wgrad_bf16(src, dy, cout, cin, first_seg=None, seg=0, *, upsample=False, scale=1.0, want_bias=True):

@@ -219,6 +219,20 @@ int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float*
 /* out = a + b (skip connections of UNetDiscriminatorSN); n multiple of 4. */
 int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* A dependency chain of 3x3 convs over one pixel grid as ONE persistent launch (bf16 path): conv k reads what convs < k wrote —
+ * the five convs of a residual dense block, rrdbnet_arch.py:32-39 (x1..x4 grow the concat buffer, conv5 closes the block).  d[0..nconv)
+ * are sr_conv3x3_bf16 descriptors with equal n / in_h / in_w.  Work items (conv, 16x32 tile) are claimed from a counter in conv-major
+ * order and wait for conv k-1 on the 3x3 tile neighbourhood (write-through stores + agent-scope flags), so ramp-up, tail and the
+ * kernel boundary are paid once per chain.  Results are bit-identical to calling sr_conv3x3_bf16 conv by conv, which is also what
+ * the entry point does when the chain is not eligible (upsampling, NCHW output, > 64 couts, ragged height, small launches,
+ * profiling) or when disabled with sr_set_conv_chain(0).
+ *   sync        device int32[sr_conv3x3_chain_sync_ints(n, h, w)], zeroed by the caller (hipMemsetAsync) before the first call that
+ *               uses it; calls sharing a block pass increasing call_index 0, 1, 2, ... < 256 and the same n / h / w
+ *   sync[0]     is raised by the kernel if a wait on a dependency timed out (bounded spins: never a hang) */
+size_t sr_conv3x3_chain_sync_ints(int n, int h, int w);
+int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);
+int sr_set_conv_chain(int enabled);
+
 /* Training input pipeline on the device: crop window + flip / transpose + uint8 -> float32 + channel swap +
  * normalisation of a batch in one launch.  Replaces, per sample on the host: paired_random_crop and augment
  * (basicsr/data/transforms.py:26-158), img2tensor (utils/img_util.py:9-35) on imfrombytes(float32=True) images (:128-132) and

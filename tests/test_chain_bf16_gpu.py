@@ -1,0 +1,119 @@
+"""sr_conv3x3_chain_bf16: the five convs of a residual dense block (rrdbnet_arch.py:32-39) as ONE persistent launch with tile-level
+hand-offs, against the same convs launched one by one (sr_conv3x3_bf16).  Both run the same tile code on the same operands in the
+same order, so the results must be BIT-identical; what the test probes is the hand-off (write-through stores, agent-scope flags,
+acquire before the dependent loads) — a stale or early read shows up as a difference.  Shapes cover the one-launch path (>= 256
+tiles of 16x32), batches with more tiles than resident workgroups, ragged widths, repeated calls on one sync block (increasing
+call_index) and the fallbacks (small launches, ragged heights), and a run under uneven load from a second stream."""
+import pytest
+import torch
+
+from image_restoration_amd import _lib
+from image_restoration_amd import hip_ops as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _rdb(dev, nf, gc, seed):
+    g = torch.Generator().manual_seed(seed)
+    packs = []
+    for k in range(1, 6):
+        cout, cin = (nf if k == 5 else gc), nf + (k - 1) * gc
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * (0.6 / (cin * 9) ** 0.5)).to(dev)
+        b = (torch.randn(cout, generator=g) * 0.05).to(dev)
+        packs.append(H.PackedConvBF16(w, b, first_seg=nf, seg=gc))
+    return packs
+
+
+def _steps(cat, nxt, packs, nf, gc, last_res2=None):
+    steps = []
+    for k in range(1, 5):
+        steps.append((cat.slice(0, nf + (k - 1) * gc), packs[k - 1], cat.slice(nf + (k - 1) * gc, gc), dict(act_slope=0.2)))
+    kw = dict(alpha=0.2, res1=cat.slice(0, nf), beta1=1.0)
+    if last_res2 is not None:
+        kw = dict(alpha=0.04, res1=cat.slice(0, nf), beta1=0.2, res2=last_res2, beta2=1.0)
+    steps.append((cat, packs[4], nxt.slice(0, nf), kw))
+    return steps
+
+
+def _fresh(dev, n, nf, gc, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    ctot = nf + 4 * gc
+    buf = torch.zeros(n, ctot // 16, h, w, 16, dtype=torch.bfloat16)
+    buf[:, :nf // 16] = torch.randn(n, nf // 16, h, w, 16, generator=g).to(torch.bfloat16)
+    buf[:, nf // 16:] = 7.0   # poison: a conv that reads x_k before it was produced sees this, not zeros
+    return H.CB16(buf.to(dev)), H.CB16(torch.full((n, ctot // 16, h, w, 16), -3.0, dtype=torch.bfloat16, device=dev))
+
+
+@pytest.mark.parametrize('n,h,w,nf,gc', [
+    (16, 128, 128, 64, 32),    # BASELINE config 2's dense block: 512 tiles = the resident workgroups
+    (40, 128, 96, 64, 32),     # 960 tiles: every workgroup claims several items per conv
+    (9, 160, 100, 64, 32),     # ragged width (last tile column 4 px wide), 360 tiles
+    (32, 64, 64, 32, 32),      # nf = 32: all five convs on the 32-cout tile
+    (2, 48, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
+    (12, 120, 128, 64, 32),    # height not a multiple of 16: fallback
+])
+def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc):
+    packs = _rdb(cuda, nf, gc, 3)
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
+    cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+    for src, pc, out, kw in _steps(cat_a, nxt_a, packs, nf, gc):
+        H.conv3x3_bf16(src, pc, out, **kw)
+    sync = None
+    for rep in range(3):       # the same sync block serves consecutive calls (a forward's dense blocks)
+        if rep:
+            cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+        _, sync = H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc), sync, call_index=rep)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0, 'a dependency wait timed out'
+        assert torch.equal(cat_a.buf, cat_b.buf), rep
+        assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
+    assert bool(torch.isfinite(nxt_b.buf[:, :nf // 16].float()).all())
+
+
+def test_chain_under_uneven_load_and_with_rrdb_residuals(cuda):
+    """Three chained dense blocks = one RRDB (the third closes with the RRDB residual, rrdbnet_arch.py:58-63) while a second stream
+    keeps part of the chip busy with unrelated bandwidth-heavy work: hand-offs must hold when workgroups are delayed unevenly."""
+    n, h, w, nf, gc = 16, 128, 128, 64, 32
+    packs = [_rdb(cuda, nf, gc, 10 + r) for r in range(3)]
+
+    def run(chain):
+        bufs = [_fresh(cuda, n, nf, gc, h, w, 21)[0] for _ in range(4)]
+        sync = None
+        for r in range(3):
+            steps = _steps(bufs[r], bufs[r + 1], packs[r], nf, gc, last_res2=bufs[0].slice(0, nf) if r == 2 else None)
+            if chain:
+                _, sync = H.conv3x3_chain_bf16(steps, sync, call_index=r)
+            else:
+                for src, pc, out, kw in steps:
+                    H.conv3x3_bf16(src, pc, out, **kw)
+        return bufs, sync
+
+    ref, _ = run(False)
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, dtype=torch.float32, device=cuda)
+    for trial in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 5 * trial):
+                noise.mul_(1.0001).add_(0.5)
+        got, sync = run(True)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        for a, b in zip(ref, got):
+            assert torch.equal(a.buf[:, :nf // 16], b.buf[:, :nf // 16]), trial
+        assert torch.equal(ref[2].buf, got[2].buf), trial
+
+
+def test_chain_can_be_switched_off(cuda):
+    lib = _lib.load()
+    n, h, w, nf, gc = 16, 64, 64, 64, 32
+    packs = _rdb(cuda, nf, gc, 1)
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 2)
+    cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 2)
+    try:
+        _lib.check(lib.sr_set_conv_chain(0), 'sr_set_conv_chain')
+        H.conv3x3_chain_bf16(_steps(cat_a, nxt_a, packs, nf, gc))
+    finally:
+        _lib.check(lib.sr_set_conv_chain(1), 'sr_set_conv_chain')
+    H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc))
+    torch.cuda.synchronize()
+    assert torch.equal(cat_a.buf, cat_b.buf) and torch.equal(nxt_a.buf[:, :4], nxt_b.buf[:, :4])

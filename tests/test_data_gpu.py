@@ -55,34 +55,26 @@ def test_device_pipeline_is_bit_identical_to_the_host_pipeline(cuda, tmp_path, m
 
 
 def test_device_crop_takes_the_reference_windows(cuda, golden):
-    """Golden G-p holds the windows the REFERENCE's paired_random_crop cut for seeds 0..15 on an index-encoded pair: the device kernel
-    given the draws of transforms.draw_window under the same seeds returns exactly those windows (as CHW float / 255)."""
+    """Golden G-p holds the LQ windows (and GT window corners) the REFERENCE's paired_random_crop cut for seeds 0..15 out of a
+    coordinate-coded 20x24 / 80x96 pair (tools/make_goldens.py g_p: channels = row, column, (row + column) % 7).  The device kernel,
+    given whole uint8 images and the draws of transforms.draw_window under the same seeds, returns exactly those windows."""
     g = golden('g_p_crop')
-    gt, lq = g['gt'], g['lq']   # float HWC images of the golden (values are small integers / 255-free encodings)
-    scale = gt.shape[0] // lq.shape[0]
-    # the golden's images are float; the kernel eats uint8 — encode positions instead and compare window ORIGINS
-    yy, xx = np.meshgrid(np.arange(lq.shape[0]), np.arange(lq.shape[1]), indexing='ij')
-    lq_u8 = np.stack([yy, xx, (yy * 7 + xx) % 251], 2).astype(np.uint8)
-    gt_u8 = lq_u8.repeat(scale, 0).repeat(scale, 1)
-    pipe = DevicePatchPipeline(dict(scale=scale, gt_size=32))
-    tops, lefts = [], []
+    yy, xx = np.meshgrid(np.arange(20), np.arange(24), indexing='ij')
+    lq_u8 = np.stack([yy, xx, (yy + xx) % 7], axis=2).astype(np.uint8)      # the golden's image, exactly representable in uint8
+    gt_u8 = lq_u8.repeat(4, 0).repeat(4, 1)
+    pipe = DevicePatchPipeline(dict(scale=4, gt_size=32))
+    windows = []
     for seed in range(16):
         random.seed(seed)
-        t, l = T.draw_window(lq.shape[0], lq.shape[1], 32 // scale)
-        tops.append(t), lefts.append(l)
-        ref_lq = g[f'lq_{seed}']
-        assert np.array_equal(ref_lq, lq[t:t + 32 // scale, l:l + 32 // scale])     # the reference cut this very window
+        windows.append(T.draw_window(20, 24, 8))
     n = 16
     batch = {'lq_u8': torch.from_numpy(np.stack([lq_u8] * n)).to(cuda), 'gt_u8': torch.from_numpy(np.stack([gt_u8] * n)).to(cuda),
-             'sym': torch.zeros(n, dtype=torch.int32, device=cuda),
-             'window': torch.tensor(list(zip(tops, lefts)), dtype=torch.int32, device=cuda)}
+             'sym': torch.zeros(n, dtype=torch.int32, device=cuda), 'window': torch.tensor(windows, dtype=torch.int32, device=cuda)}
     out = pipe(batch)
-    for k in range(n):
-        got = (out['lq'][k].cpu().numpy() * 255.).round().astype(np.int64)   # channels were swapped (BGR->RGB): plane 2 = yy, 1 = xx
-        assert got[2, 0, 0] == tops[k] and got[1, 0, 0] == lefts[k]
-        assert np.array_equal(got[2], yy[tops[k]:tops[k] + 8, lefts[k]:lefts[k] + 8])
-        big = (out['gt'][k].cpu().numpy() * 255.).round().astype(np.int64)
-        assert np.array_equal(big[1], xx[tops[k]:tops[k] + 8, lefts[k]:lefts[k] + 8].repeat(scale, 0).repeat(scale, 1))
+    back = lambda t: (t.cpu().numpy() * 255.).round().astype(np.float32).transpose(1, 2, 0)[:, :, ::-1]   # CHW RGB /255 -> HWC BGR
+    for seed in range(n):
+        assert np.array_equal(back(out['lq'][seed]), g[f'lq_{seed}']), seed
+        assert np.array_equal(back(out['gt'][seed])[::31, ::31], g[f'gt_corner_{seed}']), seed
 
 
 def test_device_feed_stages_and_augments_on_the_copy_stream(cuda, tmp_path):
