@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsr_hip.so')
+LIB_PATH = os.environ.get('SR_HIP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsr_hip.so')  # override: A/B builds of the kernels
 
 SR_ABI_VERSION = 1
 
@@ -202,6 +202,8 @@ SIGNATURES.update({
     'sr_conv3x3_chain_sync_ints': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_chain_bf16': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'sr_set_conv_chain': (C.c_int, [C.c_int]),
+    'sr_conv3x3_chain_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'sr_set_conv_chain_f32': (C.c_int, [C.c_int]),
     'sr_patch_augment_u8_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_float), C.c_void_p]),

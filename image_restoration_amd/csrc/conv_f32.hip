@@ -22,6 +22,13 @@
 // Per chunk and wave: 9*(COT+PT) ds_read_b128 feed 36*COT*PT MFMAs (64 cycles each).
 #include "sr_internal.h"
 
+// A/B switches (tools/ab_f32.sh builds the variants; measured on one box, BASELINE config 2, 20 steps):
+#ifndef SR_F32_PIPELINE
+#define SR_F32_PIPELINE 0  // operand reads of tap t+1 issued before the MFMAs of tap t: 216.5 vs 219.0 img/s without (two waves per
+#endif                     // SIMD from different workgroups already cover the LDS latency; the extra registers cost more)
+#ifndef SR_F32_SWIZZLE
+#define SR_F32_SWIZZLE 1  // LDS bank swizzle of the two 16-byte halves of a pixel / cout (see conv_bf16.hip)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -60,6 +67,10 @@ struct ConvParams {
   // for both neighbours (one pad row is all a 3x3 / parity-2x2 tap grid needs) — so tiles are not confined to one tiny
   // image.  0 = off (tiles of one image, image index from the grid).
   int stack_hs, stack_n;
+  // Weight image addressing (floats): chunk cb, tap t, cout sub-tile c of the workgroup's tile start at
+  // w + cb * w_chunk + t * w_tap + c * 256.  0 = dense image of this kernel's own COT (w_chunk = taps * COT * 256, w_tap = COT * 256);
+  // the chain kernel runs 32-cout tiles on images packed for 64-cout groups (w_tap = 512, w + 256 for the upper half).
+  int w_chunk, w_tap, w_cog;  // w_cog: floats between the images of consecutive cout groups (0 = cin_blocks * w_chunk)
 };
 
 __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
@@ -72,9 +83,18 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
 // NW = waves per workgroup (4 or 8): 8 waves share one staged weight chunk over twice the rows.
 // WT = tile width in pixels (32, 16, 8): an MFMA column group of 32 pixels is 32/WT tile rows x WT columns, so maps
 //      narrower than 32 pixels (the 16x16 ... 4x4 layers of VGGStyleDiscriminator128) do not idle 50-88 % of the lanes.
-template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4, int WT = 32>
-__global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// 16-byte store; write-through (sc1) when another workgroup of the same launch will read the tile (chain kernel).
+__device__ __forceinline__ void store16f(float* ptr, f32x4 v, bool write_through) {
+  if (write_through)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory");
+  else
+    *(f32x4*)ptr = v;
+}
+
+// One output tile of one conv: the body of conv_f32_kernel, also run once per work item by the persistent chain kernel.
+template <int COT, int PT, int KS, bool NCHW_OUT, int ABL, int NW, int WT, bool WT_OUT>
+__device__ __forceinline__ void conv_tile_f32(const ConvParams p, const int cog, const int tx, const int ty, const int n_grid,
+                                              char* smem) {
   constexpr int RPG = 32 / WT;  // tile rows per MFMA column group
   constexpr int TH = NW * PT * RPG, XROW = WT + KS - 1, XPIX = (TH + KS - 1) * XROW;
   constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024;
@@ -87,25 +107,15 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   const int j = lane & 31, h = lane >> 5;
   const int jr = j / WT, jc = j % WT;  // this lane's pixel inside a column group
 
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each
-  // XCD a contiguous run of tiles (neighbouring tiles share halo rows and weights in L2).
-  int t;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  const int tx = t % p.tiles_x;
-  t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int n_grid = t / p.tiles_y;
   const int n = n_grid;
-  const int cog = blockIdx.y;
   const int x0 = tx * WT, y0 = ty * TH;
   const int HWin = p.in_h * p.in_w;
   const bool stacked = WT < 32 && p.stack_hs > 0;
   const float* in_n = p.in + (stacked ? 0 : (long long)n * p.in_ns);
-  const float* wg = p.w + (size_t)cog * p.cin_blocks * (WBYTES / 4);
+  // weight image addressing: dense (constants) in the per-conv kernels; general (ConvParams::w_chunk / w_tap / w_cog) in the chain
+  // kernel, which runs 32-cout tiles on images packed for 64-cout groups
+  const int w_chunk = WT_OUT && p.w_chunk ? p.w_chunk : WBYTES / 4, w_tap = WT_OUT && p.w_tap ? p.w_tap : COT * 256;
+  const float* wg = p.w + (size_t)cog * (WT_OUT && p.w_cog ? (size_t)p.w_cog : (size_t)p.cin_blocks * (WBYTES / 4));
 
   // Per-lane source offsets (floats, inside one channel-block plane) of the X pieces this
   // wave moves; -1 = zero padding.
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
     // LDS bank swizzle (WT == 32): the two 16-byte halves of tile column c are stored swapped when bit 3 of c is set, so the
     // 32 lanes of one half (32-byte stride) cover all 64 banks per ds_read_b128 lane group instead of every slot twice
     // (PMC before: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); see conv_bf16.hip's header
-    const int hsw = WT == 32 ? (half ^ ((col >> 3) & 1)) : half;
+    const int hsw = (SR_F32_SWIZZLE && WT == 32) ? (half ^ ((col >> 3) & 1)) : half;
     xoff[r] = valid ? (img_off + (sy * p.in_w + sx) * 8 + hsw * 4) : -1;
   }
 
@@ -147,11 +157,11 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
         glds16(src, xs + u * 1024);
       }
     }
-    const float* wsrc = wg + (size_t)cb * (WBYTES / 4) + (lane ^ ((lane >> 4) & 1)) * 4;  // unit (cout i, half) <- half ^ bit3(i)
+    const float* wsrc = wg + (size_t)cb * w_chunk + (SR_F32_SWIZZLE ? (lane ^ ((lane >> 4) & 1)) : lane) * 4;  // unit (cout i, half) <- half ^ bit3(i)
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
-      const int u = r * NW + wave;
-      if (u < NWU) glds16(wsrc + u * 256, ws + u * 1024);
+      const int u = r * NW + wave;  // unit = tap * COT + cout sub-tile
+      if (u < NWU) glds16(wsrc + (WT_OUT ? (u / COT) * w_tap + (u % COT) * 256 : u * 256), ws + u * 1024);
     }
   };
 
@@ -168,12 +178,47 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
   int xlane[KS];
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx)
-    xlane[dx] = xrow0 + dx * 32 + ((WT == 32 ? (h ^ (((jc + dx) >> 3) & 1)) : h) * 16);
-  const int wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);  // byte offset of this lane's A operand, tap 0, cot 0
+    xlane[dx] = xrow0 + dx * 32 + (((SR_F32_SWIZZLE && WT == 32) ? (h ^ (((jc + dx) >> 3) & 1)) : h) * 16);
+  const int wlane = j * 32 + ((SR_F32_SWIZZLE ? (h ^ ((j >> 3) & 1)) : h) * 16);  // byte offset of this lane's A operand, tap 0, cot 0
 
+  // Operand reads are software-pipelined by tap: the LDS reads of tap t+1 are issued BEFORE the MFMAs of tap t (two register
+  // sets, pinned with scheduling barriers).  Left to itself hipcc issues a tap's reads behind the last MFMAs of the previous tap
+  // and then waits lgkmcnt(0): ~100 of every ~1100 cycles of a wave with nothing on the matrix pipe.
+#if SR_F32_PIPELINE
+  struct Ops {
+    f32x4 a[COT], b[PT];
+  };
+  auto load = [&](Ops& o, const char* xb, const char* ws, int tap) {
+    const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) o.a[c] = *(const f32x4*)(ws + (tap * COT + c) * 1024);
+#pragma unroll
+    for (int r = 0; r < PT; ++r) o.b[r] = *(const f32x4*)(xb + xlane[dx] + (r * RPG + dy) * XROW * 32);
+  };
+  auto mfma = [&](const Ops& o) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int r = 0; r < PT; ++r)
+          acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[c][s], o.b[r][s], acc[c][r], 0, 0, 0);
+  };
+#endif
   auto compute = [&](int buf) {
     const char* xb = smem + buf * STAGE;
     const char* ws = smem + buf * STAGE + XBYTES + wlane;
+#if SR_F32_PIPELINE
+    Ops o[2];
+    load(o[0], xb, ws, 0);
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      if (tap + 1 < KS * KS) load(o[(tap + 1) & 1], xb, ws, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(o[tap & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
 #pragma unroll
@@ -193,6 +238,7 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
               acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s], b[r][s], acc[c][r], 0, 0, 0);
       }
     }
+#endif
   };
 
   const int nchunk = p.cin_blocks;
@@ -262,11 +308,112 @@ __global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
           if constexpr (ABL & 8) {
             asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));  // timing-only: keep the value, skip the store
           } else {
-            *(f32x4*)o = v;
+            store16f(o, v, WT_OUT);
           }
         }
       }
     }
+  }
+}
+
+template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4, int WT = 32>
+__global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of tiles (neighbouring tiles share halo rows and weights in L2).
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n_grid = t / p.tiles_y;
+  conv_tile_f32<COT, PT, KS, NCHW_OUT, ABL, NW, WT, false>(p, blockIdx.y, tx, ty, n_grid, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ persistent conv chain
+// The convs of a residual dense block (rrdbnet_arch.py:32-39) as ONE launch: work items (conv k, tile, cout half) are claimed from a
+// counter in k-major order and wait until conv k-1 has finished on the tile's 3x3 neighbourhood.  Same scheme and hand-off as
+// conv_chain_bf16_kernel (conv_bf16.hip) — claimed items never depend on unclaimed ones, write-through tile stores + drained
+// waves + barrier + agent-scope progress word, one acquire before the dependent loads, bounded spins.  Why, in fp32: a conv1-4
+// launch is ONE round of 512 workgroups that start together and finish apart, so 10 % of its wave-slot time is empty (PMC:
+// SQ_WAVE_CYCLES against capacity, profiles/r02_pmc_sq_fp32.txt) and the two workgroups of a CU change tiles at the same moment;
+// in a chain the next conv's tiles fill those holes.  Every item is a 16x32 tile of 32 couts (conv5 = two items per tile).
+#define SR_CHAIN_MAX_F32 5
+struct ChainParamsF {
+  ConvParams lv[SR_CHAIN_MAX_F32];
+  int halves[SR_CHAIN_MAX_F32];   // 32-cout items per tile of conv k (1 or 2)
+  int first[SR_CHAIN_MAX_F32 + 1];  // first item of conv k; first[nconv] = number of items
+  int need[SR_CHAIN_MAX_F32];     // progress a neighbour tile must show before conv k may read it (items of convs < k)
+  int nconv, ntiles, tiles_x, tiles_y;
+  int* head;
+  int* done;
+  int* abort;
+  int epoch;
+};
+
+__global__ __launch_bounds__(256) void conv_chain_f32_kernel(const ChainParamsF P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_item;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nitems = P.first[P.nconv];
+  auto conv_of = [&](int item) {
+    int k = 0;
+    while (k + 1 < P.nconv && item >= P.first[k + 1]) ++k;
+    return k;
+  };
+  for (;;) {
+    if (wave == 0) {
+      int item = 0;
+      if (lane == 0) item = atomicAdd(P.head, 1);
+      item = __builtin_amdgcn_readfirstlane(item);
+      if (item < nitems && item >= P.first[1]) {
+        const int k = conv_of(item);
+        int t = (item - P.first[k]) / P.halves[k];
+        const int tx = t % P.tiles_x;
+        t /= P.tiles_x;
+        const int ty = t % P.tiles_y, n = t / P.tiles_y;
+        bool gave_up = false;
+        if (lane < 9) {
+          const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+          if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) {
+            const int* f = P.done + (n * P.tiles_y + ny) * P.tiles_x + nx;
+            const int want = P.epoch + P.need[k];
+            int spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+              __builtin_amdgcn_s_sleep(2);
+              if ((++spins & 255) == 0 && (spins > (1 << 22) || __hip_atomic_load(P.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(P.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+              }
+            }
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(gave_up)) item = nitems;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (lane == 0) s_item = item;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nitems) break;
+    const int k = conv_of(item);
+    const int sub = (item - P.first[k]) % P.halves[k];
+    int t = (item - P.first[k]) / P.halves[k];
+    const int tile = t;
+    const int tx = t % P.tiles_x;
+    t /= P.tiles_x;
+    const int ty = t % P.tiles_y, n = t / P.tiles_y;
+    conv_tile_f32<1, 4, 3, false, 0, 4, 32, true>(P.lv[k], sub, tx, ty, n, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(P.done + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -512,6 +659,90 @@ int launch_small(ConvParams q, const sr_conv3x3_desc* d, int groups, int gc, hip
 }
 
 }  // namespace
+
+// Off by default: 221.0 vs 223.0 img/s conv by conv on the same box (BASELINE config 2).  The chain fills the 10 % of empty
+// wave-slot time of the one-round conv1-4 launches, but runs conv5 as two 32-cout items and pays the hand-offs.
+static bool g_chain_f32_enabled = false;
+extern "C" int sr_set_conv_chain_f32(int enabled) {
+  g_chain_f32_enabled = enabled != 0;
+  return SR_OK;
+}
+
+// fp32 twin of sr_conv3x3_chain_bf16 (conv_bf16.hip): same contract, same sync block (sr_conv3x3_chain_sync_ints).
+extern "C" int sr_conv3x3_chain_f32(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_f32: bad argument");
+  constexpr int kEpochs = 256;  // SR_CHAIN_EPOCHS of conv_bf16.hip: layout of the sync block
+  bool one_launch = g_chain_f32_enabled && sync && nconv >= 2 && nconv <= SR_CHAIN_MAX_F32 && call_index >= 0 && call_index < kEpochs &&
+                    !sr::prof_on();
+  for (int k = 0; k < nconv && one_launch; ++k) {
+    const sr_conv3x3_desc& c = d[k];
+    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && !c.accumulate &&
+                 c.cout <= 64 && c.in_h % 16 == 0 && c.s2_channels == 0;
+  }
+  const int conc = sr::launch_concurrency();
+  if (one_launch) one_launch = (long long)sr::cdiv(d[0].in_w, 32) * (d[0].in_h / 16) * d[0].n * conc >= 512;
+  if (!one_launch) {
+    for (int k = 0; k < nconv; ++k)
+      if (int rc = sr_conv3x3_f32(&d[k], stream_)) return rc;
+    return SR_OK;
+  }
+  ChainParamsF P = {};
+  P.nconv = nconv;
+  int items = 0, progress = 0;
+  for (int k = 0; k < nconv; ++k) {
+    ConvParams& p = P.lv[k];
+    if (int rc = fill_common(&d[k], &p, "sr_conv3x3_chain_f32")) return rc;
+    p.H = p.vH = p.oH = d[k].in_h;
+    p.W = p.vW = p.oW = d[k].in_w;
+    p.tap_oy = p.tap_ox = -1;
+    p.tiles_x = sr::cdiv(p.W, 32);
+    p.tiles_y = p.H / 16;
+    if (int rc = check_sizes(p, d[k].n, "sr_conv3x3_chain_f32")) return rc;
+    const int gc = sr::conv_group_couts(d[k].cout);  // how the weight image was packed: 32- or 64-cout groups
+    P.halves[k] = gc == 64 ? 2 : 1;
+    if (gc == 64) {
+      p.w_chunk = 9 * 2 * 256;
+      p.w_tap = 2 * 256;
+      p.w_cog = 256;
+    }
+    P.first[k] = items;
+    P.need[k] = progress;
+    if (k == 0) {
+      P.tiles_x = p.tiles_x;
+      P.tiles_y = p.tiles_y;
+      P.ntiles = p.tiles_x * p.tiles_y * d[0].n;
+    }
+    items += P.ntiles * P.halves[k];
+    progress += P.halves[k];
+  }
+  P.first[nconv] = items;
+
+  P.abort = sync;
+  P.head = sync + 1 + call_index;
+  P.done = sync + 1 + kEpochs;
+  // the progress words count finished items and are never reset between the calls that share the block: every call adds
+  // `progress` per tile, so call i starts from i * progress (calls sharing a block have the same chain shape)
+  P.epoch = call_index * progress;
+  constexpr int lds = conv_lds_bytes<1, 4, 3, 4, 32>();
+  auto kern = conv_chain_f32_kernel;
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;
+  static int slots[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (slots[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    slots[dev] = (per_cu > 2 ? 2 : per_cu) * cus;
+  }
+  long long grid = slots[dev] / (conc > 1 ? conc : 1);
+  if (grid > P.ntiles) grid = P.ntiles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, P);
+  SR_CHECK_LAUNCH("conv_chain_f32 launch");
+  return SR_OK;
+}
 
 extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -102,8 +102,11 @@ struct Carver {
 struct FwdSpace {
   float *xin, *feat0, *trunk, *up1, *up2, *hr, *last;
   std::vector<float*> cat;
+  int32_t* sync;     // hand-off words of the dense-block chain launches (sr_conv3x3_chain_f32), one block per image group
+  size_t sync_ints;  // ints per block
   size_t bytes;
 };
+constexpr int kSyncBlocks = 4;
 
 FwdSpace carve_fwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int w, char* base, bool train) {
   FwdSpace W;
@@ -119,6 +122,8 @@ FwdSpace carve_fwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int 
   W.up2 = cv.take((size_t)n * P.nfp * hw * 16);
   W.hr = cv.take((size_t)n * P.nfp * hw * 16);
   W.last = c->num_out_ch > 4 ? cv.take((size_t)n * r8(c->num_out_ch) * hw * 16) : nullptr;
+  W.sync_ints = sr_conv3x3_chain_sync_ints(n, h, w);
+  W.sync = (int32_t*)cv.take(W.sync_ints * kSyncBlocks);  // take() counts floats: same size as int32
   W.bytes = cv.off;
   return W;
 }
@@ -150,7 +155,7 @@ BwdSpace carve_bwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int 
 
 // The launch sequence of one forward over images [0, n) of the (already carved / shifted) workspace.
 int forward_body(const sr_rrdbnet_cfg* cfg, const NetPlan& P, const FwdSpace& W, const float* packed, const float* x,
-                 float* y, int n, int h, int w, hipStream_t stream, bool train) {
+                 float* y, int n, int h, int w, hipStream_t stream, bool train, int32_t* sync) {
   const long long hw = (long long)h * w;
   const int ctot = P.nfp + 4 * P.gcp;
   const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;
@@ -210,21 +215,47 @@ int forward_body(const sr_rrdbnet_cfg* cfg, const NetPlan& P, const FwdSpace& W,
       return SR_ELAUNCH;
     }
   }
-  // body (:113): 3 RDBs per RRDB
+  // body (:113): 3 RDBs per RRDB, each dense block ONE launch (sr_conv3x3_chain_f32: conv1..conv5 with tile-level hand-offs;
+  // the entry point runs the five convs one by one when the shape is not eligible)
+  auto desc = [&](const float* in, float* out, float slope, float alpha, const float* r1, float b1, const float* r2, float b2) {
+    const ConvPlan& cp = P.convs[ci++];
+    sr_conv3x3_desc d = {};
+    d.in = in;
+    d.in_img_stride = cat_ns;
+    d.cin_pad = cp.cin_pad;
+    d.cin_real = cp.cin;
+    d.in_h = h;
+    d.in_w = w;
+    d.wpacked = packed + cp.w_off;
+    d.bpacked = packed + cp.b_off;
+    d.cout = cp.cout;
+    d.out = out;
+    d.out_img_stride = cat_ns;
+    d.n = n;
+    d.act_slope = slope;
+    d.alpha = alpha;
+    d.res1 = r1;
+    d.res1_img_stride = cat_ns;
+    d.beta1 = b1;
+    d.res2 = r2;
+    d.res2_img_stride = cat_ns;
+    d.beta2 = b2;
+    return d;
+  };
+  int chain_call = 0;
   for (int b = 0; b < cfg->num_block; ++b) {
     const float* x_rrdb = cat(3 * b);
     for (int r = 0; r < 3; ++r) {
       float* buf = cat(3 * b + r);
       float* nxt = cat(3 * b + r + 1);
-      for (int k = 1; k <= 4; ++k) {  // x_k = lrelu(conv_k(cat(x, x1..x_{k-1})))  (:33-36)
-        rc = conv(buf, cat_ns, h, w, 0, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, cat_ns, 0.2f, 1.f, nullptr, 0,
-                  0.f, nullptr, 0, 0.f, 0);
-        if (rc) return rc;
-      }
+      sr_conv3x3_desc d[5];
+      for (int k = 1; k <= 4; ++k)  // x_k = lrelu(conv_k(cat(x, x1..x_{k-1})))  (:33-36)
+        d[k - 1] = desc(buf, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, 0.2f, 1.f, nullptr, 0.f, nullptr, 0.f);
       if (r < 2)  // x5*0.2 + x (:39)
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f, 0);
+        d[4] = desc(buf, nxt, 1.f, 0.2f, buf, 1.f, nullptr, 0.f);
       else  // (x5*0.2 + x)*0.2 + x_rrdb (:39, :63)
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f, 0);
+        d[4] = desc(buf, nxt, 1.f, 0.04f, buf, 0.2f, x_rrdb, 1.f);
+      rc = sr_conv3x3_chain_f32(d, 5, sync, chain_call++, stream);
       if (rc) return rc;
     }
   }
@@ -297,12 +328,17 @@ int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x,
   if (groups == 0) groups = 1;  // fp32 default: no grouping (include/sr_hip.h)
   while (groups > 1 && (n / groups) * wg_per_image < 512) --groups;
   if (groups > n) groups = n;
-  if (groups <= 1 || sr::prof_on()) return forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train);
+  if (hipMemsetAsync(W.sync, 0, W.sync_ints * kSyncBlocks * sizeof(int32_t), stream) != hipSuccess) {
+    sr::set_error("sr_rrdbnet_forward: sync memset failed");
+    return SR_ELAUNCH;
+  }
+  if (groups <= 1 || sr::prof_on()) return forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train, W.sync);
   const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
   const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
-  return sr::run_image_groups(n, groups, stream, [&](int, int n0, int cnt, hipStream_t s) {
+  return sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
     const FwdSpace S = shift_space(cfg, P, W, n0, h, w);
-    return forward_body(cfg, P, S, packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train);
+    return forward_body(cfg, P, S, packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train,
+                        W.sync + (size_t)(g % kSyncBlocks) * W.sync_ints);
   });
 }
 

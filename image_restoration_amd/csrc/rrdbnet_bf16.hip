@@ -83,8 +83,11 @@ struct CarverH {
 struct FwdSpaceH {
   __bf16 *xin, *feat0, *trunk, *up1, *up2, *hr;
   std::vector<__bf16*> cat;
+  int32_t* sync;      // hand-off words of the dense-block chain launches (sr_conv3x3_chain_bf16), one block per image group
+  size_t sync_ints;   // ints per block
   size_t bytes;
 };
+constexpr int kSyncBlocks = 4;  // image groups of a forward (sr_set_forward_groups <= 4)
 // train = false: 4 rotating concat buffers; train = true: one per RDB + 1 (they are the saved activations)
 FwdSpaceH carve_fwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, int w, char* base, bool train) {
   FwdSpaceH W;
@@ -99,6 +102,8 @@ FwdSpaceH carve_fwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
   W.up1 = cv.take((size_t)n * P.nfp * hw * 4);
   W.up2 = cv.take((size_t)n * P.nfp * hw * 16);
   W.hr = cv.take((size_t)n * P.nfp * hw * 16);
+  W.sync_ints = sr_conv3x3_chain_sync_ints(n, h, w);
+  W.sync = (int32_t*)cv.take(W.sync_ints * kSyncBlocks * 2);  // take() counts 2-byte elements
   W.bytes = cv.off;
   return W;
 }
@@ -131,7 +136,7 @@ BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
 
 // One image range of the forward on one stream; W already points at the range's first image in every buffer.
 int forward_body_h(const sr_rrdbnet_cfg* cfg, const NetPlanH& P, const FwdSpaceH& W, const void* packed, const float* x, float* y,
-                   int n, int h, int w, hipStream_t stream, bool train, const char* who) {
+                   int n, int h, int w, hipStream_t stream, bool train, const char* who, int32_t* sync) {
   const long long hw = (long long)h * w;
   const int ctot = P.nfp + 4 * P.gcp;
   const long long cat_ns = (long long)ctot * hw, feat_ns = (long long)P.nfp * hw;  // bf16 elements
@@ -182,20 +187,48 @@ int forward_body_h(const sr_rrdbnet_cfg* cfg, const NetPlanH& P, const FwdSpaceH
       return SR_ELAUNCH;
     }
   }
+  // One launch per residual dense block (sr_conv3x3_chain_bf16: conv1..conv5 with tile-level hand-offs; it falls back to five
+  // launches by itself when the shape is not eligible).
+  auto desc = [&](const __bf16* in, long long in_ns, void* out, long long out_ns, float slope, float alpha, const __bf16* r1,
+                  long long r1_ns, float b1, const __bf16* r2, long long r2_ns, float b2) {
+    const ConvPlanH& cp = P.convs[ci++];
+    sr_conv3x3_desc d = {};
+    d.in = (const float*)in;
+    d.in_img_stride = in_ns;
+    d.cin_pad = cp.cin_pad;
+    d.cin_real = cp.cin;
+    d.in_h = h;
+    d.in_w = w;
+    d.wpacked = (const float*)((const char*)packed + cp.w_off);
+    d.bpacked = (const float*)((const char*)packed + cp.b_off);
+    d.cout = cp.cout;
+    d.out = (float*)out;
+    d.out_img_stride = out_ns;
+    d.n = n;
+    d.act_slope = slope;
+    d.alpha = alpha;
+    d.res1 = (const float*)r1;
+    d.res1_img_stride = r1_ns;
+    d.beta1 = b1;
+    d.res2 = (const float*)r2;
+    d.res2_img_stride = r2_ns;
+    d.beta2 = b2;
+    return d;
+  };
+  int chain_call = 0;
   for (int b = 0; b < cfg->num_block; ++b) {
     const __bf16* x_rrdb = catbuf(3 * b);
     for (int r = 0; r < 3; ++r) {
       __bf16* buf = catbuf(3 * b + r);
       __bf16* nxt = catbuf(3 * b + r + 1);
-      for (int k = 1; k <= 4; ++k) {
-        rc = conv(buf, cat_ns, h, w, 0, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, cat_ns, 0.2f, 1.f, nullptr, 0, 0.f,
-                  nullptr, 0, 0.f, 0);
-        if (rc) return rc;
-      }
+      sr_conv3x3_desc d[5];
+      for (int k = 1; k <= 4; ++k)
+        d[k - 1] = desc(buf, cat_ns, buf + (long long)(P.nfp + (k - 1) * P.gcp) * hw, cat_ns, 0.2f, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f);
       if (r < 2)
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f, 0);
+        d[4] = desc(buf, cat_ns, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f);
       else
-        rc = conv(buf, cat_ns, h, w, 0, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f, 0);
+        d[4] = desc(buf, cat_ns, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f);
+      rc = sr_conv3x3_chain_bf16(d, 5, sync, chain_call++, stream);
       if (rc) return rc;
     }
   }
@@ -247,12 +280,17 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
   if (groups == 0) groups = train ? 1 : 4;  // the training forward (one saved buffer per dense block) measured no gain
   const long long wg_per_image = (long long)sr::cdiv(w, 32) * sr::cdiv(h, 32);
   while (groups > 1 && (n / groups) * wg_per_image < 64) --groups;
-  if (groups <= 1 || sr::prof_on()) return forward_body_h(cfg, P, W, packed, x, y, n, h, w, stream, train, who);
+  // hand-off words of the chain launches: zero once per forward, before the image groups fork
+  if (hipMemsetAsync(W.sync, 0, W.sync_ints * kSyncBlocks * sizeof(int32_t), stream) != hipSuccess) {
+    sr::set_error("%s: sync memset failed", who);
+    return SR_ELAUNCH;
+  }
+  if (groups <= 1 || sr::prof_on()) return forward_body_h(cfg, P, W, packed, x, y, n, h, w, stream, train, who, W.sync);
   const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
   const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
-  return sr::run_image_groups(n, groups, stream, [&](int, int n0, int cnt, hipStream_t s) {
+  return sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
     return forward_body_h(cfg, P, shift_space_h(P, W, n0, h, w), packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train,
-                          who);
+                          who, W.sync + (size_t)(g % kSyncBlocks) * W.sync_ints);
   });
 }
 }  // namespace

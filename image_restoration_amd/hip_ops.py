@@ -124,13 +124,8 @@ class PackedConv:
                        'sr_conv3x3_pack_f32')
 
 
-def conv3x3(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-            beta2=0.0, accumulate=False, mask=None, mask_cb0=0, mask_slope=0.2, out_nchw=None):
-    """out = alpha*lrelu(conv(src)+bias) + beta1*res1 + beta2*res2  (one sr_conv3x3_f32 launch).
-
-    src: CB8 window of pc.src_channels channels.  out: CB8 window (allocated if None) or, with
-    ``out_nchw`` = an NCHW tensor [N, cout<=4, H, W], a plain tensor."""
-    lib = _lib.load()
+def _conv_desc_f32(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
+                   beta2=0.0, accumulate=False, mask=None, mask_cb0=0, mask_slope=0.2, out_nchw=None):
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
     H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
     d = _lib.ConvDesc()
@@ -156,9 +151,36 @@ def conv3x3(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1
     if mask is not None:
         d.mask_src, d.mask_img_stride, d.mask_cb0, d.mask_cbn, d.mask_slope = (mask.ptr, mask.img_stride, mask_cb0,
                                                                                mask.cbn, mask_slope)
+    return d, ret
+
+
+def conv3x3(src, pc, out=None, **kw):
+    """out = alpha*lrelu(conv(src)+bias) + beta1*res1 + beta2*res2  (one sr_conv3x3_f32 launch).
+
+    src: CB8 window of pc.src_channels channels.  out: CB8 window (allocated if None) or, with
+    ``out_nchw`` = an NCHW tensor [N, cout<=4, H, W], a plain tensor.  Keywords: upsample, act_slope, alpha, res1/beta1,
+    res2/beta2, accumulate, mask/mask_cb0/mask_slope, out_nchw."""
+    lib = _lib.load()
+    d, ret = _conv_desc_f32(src, pc, out, **kw)
     with torch.cuda.device(src.device):
         _lib.check(lib.sr_conv3x3_f32(C.byref(d), _stream(src.device)), 'sr_conv3x3_f32')
     return ret
+
+
+def conv3x3_chain(steps, sync=None, call_index=0):
+    """fp32 twin of conv3x3_chain_bf16 — sr_conv3x3_chain_f32.  ``steps`` = [(src CB8, PackedConv, out CB8, kwargs of conv3x3)]."""
+    lib = _lib.load()
+    src0 = steps[0][0]
+    if sync is None:
+        sync = torch.zeros(lib.sr_conv3x3_chain_sync_ints(src0.n, src0.h, src0.w), dtype=torch.int32, device=src0.device)
+    descs = (_lib.ConvDesc * len(steps))()
+    outs = []
+    for i, (src, pc, out, kw) in enumerate(steps):
+        descs[i], ret = _conv_desc_f32(src, pc, out, **kw)
+        outs.append(ret)
+    with torch.cuda.device(src0.device):
+        _lib.check(lib.sr_conv3x3_chain_f32(descs, len(steps), sync.data_ptr(), call_index, _stream(src0.device)), 'sr_conv3x3_chain_f32')
+    return outs, sync
 
 
 def conv3x3_wgrad(src, dy, cout, cin, first_seg=None, seg=0, *, upsample=False, scale=1.0, want_bias=True):

@@ -232,6 +232,10 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
 size_t sr_conv3x3_chain_sync_ints(int n, int h, int w);
 int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);
 int sr_set_conv_chain(int enabled);
+/* fp32 twin: same contract and sync block layout; the calls that share a block must be chains of the same shape (cout of every
+ * conv), and a block is used by one precision at a time. */
+int sr_conv3x3_chain_f32(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);
+int sr_set_conv_chain_f32(int enabled);
 
 /* Training input pipeline on the device: crop window + flip / transpose + uint8 -> float32 + channel swap +
  * normalisation of a batch in one launch.  Replaces, per sample on the host: paired_random_crop and augment

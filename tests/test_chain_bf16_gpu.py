@@ -2,7 +2,7 @@
 hand-offs, against the same convs launched one by one (sr_conv3x3_bf16).  Both run the same tile code on the same operands in the
 same order, so the results must be BIT-identical; what the test probes is the hand-off (write-through stores, agent-scope flags,
 acquire before the dependent loads) — a stale or early read shows up as a difference.  Shapes cover the one-launch path (>= 256
-tiles of 16x32), batches with more tiles than resident workgroups, ragged widths, repeated calls on one sync block (increasing
+tiles of 32x32), batches with more tiles than resident workgroups, ragged widths, repeated calls on one sync block (increasing
 call_index) and the fallbacks (small launches, ragged heights), and a run under uneven load from a second stream."""
 import pytest
 import torch
@@ -11,6 +11,15 @@ from image_restoration_amd import _lib
 from image_restoration_amd import hip_ops as H
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def chain_on():
+    """The chain launch is opt-in (sr_set_conv_chain*): on for these tests, restored afterwards."""
+    lib = _lib.load()
+    _lib.check(lib.sr_set_conv_chain(1), 'sr_set_conv_chain')
+    yield
+    _lib.check(lib.sr_set_conv_chain(0), 'sr_set_conv_chain')
 
 
 def _rdb(dev, nf, gc, seed):
@@ -45,12 +54,12 @@ def _fresh(dev, n, nf, gc, h, w, seed):
 
 
 @pytest.mark.parametrize('n,h,w,nf,gc', [
-    (16, 128, 128, 64, 32),    # BASELINE config 2's dense block: 512 tiles = the resident workgroups
-    (40, 128, 96, 64, 32),     # 960 tiles: every workgroup claims several items per conv
-    (9, 160, 100, 64, 32),     # ragged width (last tile column 4 px wide), 360 tiles
-    (32, 64, 64, 32, 32),      # nf = 32: all five convs on the 32-cout tile
-    (2, 48, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
-    (12, 120, 128, 64, 32),    # height not a multiple of 16: fallback
+    (16, 128, 128, 64, 32),    # BASELINE config 2's dense block: 256 tiles of 32x32 = one per CU
+    (40, 128, 96, 64, 32),     # 480 tiles: every workgroup claims several items per conv
+    (12, 160, 100, 64, 32),    # ragged width (last tile column 4 px wide), 240 tiles
+    (64, 64, 64, 32, 32),      # nf = 32: all five convs on the 32-cout tile
+    (2, 64, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
+    (12, 120, 128, 64, 32),    # height not a multiple of 32: fallback
 ])
 def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc):
     packs = _rdb(cuda, nf, gc, 3)
@@ -109,11 +118,9 @@ def test_chain_can_be_switched_off(cuda):
     packs = _rdb(cuda, nf, gc, 1)
     cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 2)
     cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 2)
-    try:
-        _lib.check(lib.sr_set_conv_chain(0), 'sr_set_conv_chain')
-        H.conv3x3_chain_bf16(_steps(cat_a, nxt_a, packs, nf, gc))
-    finally:
-        _lib.check(lib.sr_set_conv_chain(1), 'sr_set_conv_chain')
+    _lib.check(lib.sr_set_conv_chain(0), 'sr_set_conv_chain')
+    H.conv3x3_chain_bf16(_steps(cat_a, nxt_a, packs, nf, gc))
+    _lib.check(lib.sr_set_conv_chain(1), 'sr_set_conv_chain')
     H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc))
     torch.cuda.synchronize()
     assert torch.equal(cat_a.buf, cat_b.buf) and torch.equal(nxt_a.buf[:, :4], nxt_b.buf[:, :4])

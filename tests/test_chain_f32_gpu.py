@@ -1,0 +1,131 @@
+"""sr_conv3x3_chain_f32: a residual dense block (rrdbnet_arch.py:32-39) as ONE persistent fp32 launch against the same convs launched
+one by one.  The chain runs conv5 as two 32-cout work items per tile on the 64-cout weight image, the per-conv path as one 64-cout
+tile: each output value is the same fp32 fma chain over k = (cin block, tap, channel) in the same order either way, so the results
+must be BIT-identical; differences would come from the hand-off (stale or early reads).  Also: repeated calls on one sync block,
+more tiles than resident workgroups, ragged width, fallbacks, and the whole network with the chain switched off and on."""
+import numpy as np
+import pytest
+import torch
+
+import image_restoration_amd as ira
+from image_restoration_amd import _lib
+from image_restoration_amd import hip_ops as H
+from image_restoration_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def chain_on():
+    """The chain launch is opt-in (sr_set_conv_chain*): on for these tests, restored afterwards."""
+    lib = _lib.load()
+    _lib.check(lib.sr_set_conv_chain_f32(1), 'sr_set_conv_chain_f32')
+    yield
+    _lib.check(lib.sr_set_conv_chain_f32(0), 'sr_set_conv_chain_f32')
+
+
+def _rdb(dev, nf, gc, seed):
+    g = torch.Generator().manual_seed(seed)
+    packs = []
+    for k in range(1, 6):
+        cout, cin = (nf if k == 5 else gc), nf + (k - 1) * gc
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * (0.6 / (cin * 9) ** 0.5)).to(dev)
+        b = (torch.randn(cout, generator=g) * 0.05).to(dev)
+        packs.append(H.PackedConv(w, b, first_seg=nf, seg=gc))
+    return packs
+
+
+def _steps(cat, nxt, packs, nf, gc, last_res2=None):
+    steps = []
+    for k in range(1, 5):
+        steps.append((cat.slice(0, nf + (k - 1) * gc), packs[k - 1], cat.slice(nf + (k - 1) * gc, gc), dict(act_slope=0.2)))
+    kw = dict(alpha=0.2, res1=cat.slice(0, nf), beta1=1.0)
+    if last_res2 is not None:
+        kw = dict(alpha=0.04, res1=cat.slice(0, nf), beta1=0.2, res2=last_res2, beta2=1.0)
+    steps.append((cat, packs[4], nxt.slice(0, nf), kw))
+    return steps
+
+
+def _fresh(dev, n, nf, gc, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    ctot = nf + 4 * gc
+    buf = torch.full((n, ctot // 8, h, w, 8), 7.0)      # poison: a conv that reads x_k before it was produced sees this
+    buf[:, :nf // 8] = torch.randn(n, nf // 8, h, w, 8, generator=g)
+    return H.CB8(buf.to(dev)), H.CB8(torch.full((n, ctot // 8, h, w, 8), -3.0, device=dev))
+
+
+@pytest.mark.parametrize('n,h,w,nf,gc', [
+    (16, 128, 128, 64, 32),    # BASELINE config 2's dense block: 512 tiles of 16x32, 6 work items each
+    (20, 128, 96, 64, 32),     # 480 tiles: below the 512-tile threshold, conv-by-conv fallback
+    (40, 128, 96, 64, 32),     # 960 tiles
+    (24, 96, 100, 64, 32),     # ragged width, 576 tiles
+    (64, 64, 64, 32, 32),      # nf = 32: conv5 is a single 32-cout item too
+    (2, 64, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
+    (40, 120, 128, 64, 32),    # height not a multiple of 16: fallback
+])
+def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc):
+    packs = _rdb(cuda, nf, gc, 3)
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
+    for src, pc, out, kw in _steps(cat_a, nxt_a, packs, nf, gc):
+        H.conv3x3(src, pc, out, **kw)
+    sync = None
+    for rep in range(3):
+        cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+        _, sync = H.conv3x3_chain(_steps(cat_b, nxt_b, packs, nf, gc), sync, call_index=rep)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0, 'a dependency wait timed out'
+        assert torch.equal(cat_a.buf, cat_b.buf), rep
+        assert torch.equal(nxt_a.buf[:, :nf // 8], nxt_b.buf[:, :nf // 8]), rep
+    assert bool(torch.isfinite(nxt_b.buf[:, :nf // 8]).all())
+
+
+def test_chain_under_uneven_load_with_rrdb_residuals(cuda):
+    n, h, w, nf, gc = 16, 128, 128, 64, 32
+    packs = [_rdb(cuda, nf, gc, 10 + r) for r in range(3)]
+
+    def run(chain):
+        bufs = [_fresh(cuda, n, nf, gc, h, w, 21)[0] for _ in range(4)]
+        sync = None
+        for r in range(3):
+            steps = _steps(bufs[r], bufs[r + 1], packs[r], nf, gc, last_res2=bufs[0].slice(0, nf) if r == 2 else None)
+            if chain:
+                _, sync = H.conv3x3_chain(steps, sync, call_index=r)
+            else:
+                for src, pc, out, kw in steps:
+                    H.conv3x3(src, pc, out, **kw)
+        return bufs, sync
+
+    ref, _ = run(False)
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, dtype=torch.float32, device=cuda)
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(10 + 20 * trial):
+                noise.mul_(1.0001).add_(0.5)
+        got, sync = run(True)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        for a, b in zip(ref, got):
+            assert torch.equal(a.buf[:, :nf // 8], b.buf[:, :nf // 8]), trial
+        assert torch.equal(ref[2].buf, got[2].buf), trial
+
+
+def test_network_forward_is_identical_with_and_without_chain_launches(cuda):
+    """BASELINE config 2's network (23 blocks, nf 64) on a batch of 16 128x128 tiles: dense blocks as chain launches (default) vs
+    conv by conv — the same output bit for bit, in fp32 and bf16."""
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32)
+    net = ira.build_network(dict(type='RRDBNet', **cfg)).to(cuda).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **cfg).items()}, strict=True)
+    x = torch.from_numpy(synth.uniform_input(1234, (16, 3, 128, 128))).to(cuda)
+    lib = _lib.load()
+    for dtype, switch in (('fp32', lib.sr_set_conv_chain_f32), ('bf16', lib.sr_set_conv_chain)):
+        net.set_compute_dtype(dtype)
+        with torch.no_grad():
+            try:
+                _lib.check(switch(1), 'switch')
+                y_chain = net(x).clone()
+            finally:
+                _lib.check(switch(0), 'switch')
+            y_plain = net(x).clone()
+        assert torch.equal(y_chain, y_plain), dtype
+        assert bool(torch.isfinite(y_chain).all())

@@ -42,7 +42,43 @@ def bench(n, h, w, iters=30, nf=64, gc=32):
           f'({fl / res["chain"] / 1e6:.0f} TF)   x{res["conv-by-conv"] / res["chain"]:.2f}', flush=True)
 
 
+def bench_f32(n, h, w, iters=10, nf=64, gc=32):
+    import test_chain_f32_gpu as T
+    dev = torch.device('cuda')
+    packs = T._rdb(dev, nf, gc, 3)
+    cat, nxt = T._fresh(dev, n, nf, gc, h, w, 5)
+    steps = T._steps(cat, nxt, packs, nf, gc)
+    res = {}
+    for name in ('conv-by-conv', 'chain'):
+        sync = None
+        for it in range(2):
+            if name == 'chain':
+                _, sync = H.conv3x3_chain(steps, None, 0)
+            else:
+                for src, pc, out, kw in steps:
+                    H.conv3x3(src, pc, out, **kw)
+        torch.cuda.synchronize()
+        sync = torch.zeros_like(sync) if sync is not None else None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for it in range(iters):
+            if name == 'chain':
+                H.conv3x3_chain(steps, sync, it)
+            else:
+                for src, pc, out, kw in steps:
+                    H.conv3x3(src, pc, out, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) * 1e3 / iters
+        assert sync is None or int(sync[0]) == 0
+    fl = 2.0 * 9 * n * h * w * sum((nf + k * gc) * (nf if k == 4 else gc) for k in range(5))
+    print(f'fp32 n={n} {h}x{w}: conv-by-conv {res["conv-by-conv"]:.1f} us ({fl / res["conv-by-conv"] / 1e6:.1f} TF)   chain {res["chain"]:.1f} us '
+          f'({fl / res["chain"] / 1e6:.1f} TF)   x{res["conv-by-conv"] / res["chain"]:.3f}', flush=True)
+
+
 if __name__ == '__main__':
+    bench_f32(16, 128, 128)
+    bench_f32(32, 128, 128)
     bench(16, 128, 128)
     bench(4, 128, 128)
     bench(32, 128, 128)
