@@ -317,7 +317,7 @@ __device__ __forceinline__ void conv_tile_f32(const ConvParams p, const int cog,
 }
 
 template <int COT, int PT, int KS, bool NCHW_OUT, int ABL = 0, int NW = 4, int WT = 32>
-__global__ __launch_bounds__(NW * 64) void conv_f32_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NW * 64, (COT == 2 && PT == 4) ? 2 : 1) void conv_f32_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each
   // XCD a contiguous run of tiles (neighbouring tiles share halo rows and weights in L2).
@@ -663,6 +663,11 @@ int launch_small(ConvParams q, const sr_conv3x3_desc* d, int groups, int gc, hip
 // Off by default: 221.0 vs 223.0 img/s conv by conv on the same box (BASELINE config 2).  The chain fills the 10 % of empty
 // wave-slot time of the one-round conv1-4 launches, but runs conv5 as two 32-cout items and pays the hand-offs.
 static bool g_chain_f32_enabled = false;
+static bool g_f32_tall64 = false;
+extern "C" int sr_dev_set_f32_tall64(int on) {  // development switch (not in the ABI header)
+  g_f32_tall64 = on != 0;
+  return SR_OK;
+}
 extern "C" int sr_set_conv_chain_f32(int enabled) {
   g_chain_f32_enabled = enabled != 0;
   return SR_OK;
@@ -795,7 +800,16 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
     p.tiles_y = sr::cdiv(p.H, 4);
     return gc == 64 ? launch<2, 1, 3, false>(p, d->n, groups, stream, d) : launch<1, 1, 3, false>(p, d->n, groups, stream, d);
   }
-  if (gc == 64) return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
+  if (gc == 64) {
+    // 64-cout groups on 16-row tiles (PT = 4: 128 accumulator registers): half the weight refill per MFMA and one round of
+    // workgroups instead of two, when the launch still fills the chip (A/B: sr_set_f32_tall64)
+    const long long wg16 = (long long)p.tiles_x * sr::cdiv(p.H, 16) * d->n * groups;
+    if (g_f32_tall64 && p.H % 16 == 0 && wg16 >= 512) {
+      p.tiles_y = sr::cdiv(p.H, 16);
+      return launch<2, 4, 3, false>(p, d->n, groups, stream, d);
+    }
+    return launch<2, PT, 3, false>(p, d->n, groups, stream, d);
+  }
   // 32-cout groups: 16-row tiles (PT = 4) halve the weight refill per MFMA (measured +2.5..7 % on the RDB conv1-4
   // shapes, tools/conv_ablate.hip) as long as the launch still has >= 2 workgroups per CU and rows are not wasted.
   const long long wg4 = (long long)p.tiles_x * sr::cdiv(p.H, 16) * d->n * groups;

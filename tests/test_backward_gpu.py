@@ -163,3 +163,44 @@ def test_requires_grad_toggle_and_no_input_grad(cuda):
         p.requires_grad_(True)
     net(x).sum().backward()  # accumulates like any autograd leaf
     assert torch.allclose(net.conv_last.weight.grad, 2 * g1, rtol=1e-6, atol=0)
+
+
+def test_rrdb_forward_and_backward_vs_reference_golden(cuda, golden):
+    """G-c: ONE RRDB (rrdbnet_arch.py:42-63) forward / backward on the product path — RRDBNet.forward under autograd
+    (archs/rrdbnet_autograd.py -> sr_rrdbnet_forward_train_f32 / sr_rrdbnet_backward_f32) — against the reference's own output, input
+    gradient, 30 parameter-gradient norms and three full gradients.
+
+    The C ABI runs whole networks, so the block is isolated by construction instead of by a special entry point: a 1-block network with
+    num_in_ch = num_out_ch = num_feat = 64 whose six other convs are identities (centre tap = I) and whose head stays in LeakyReLU's
+    linear regime (bias +8 on conv_up1 keeps every pre-activation positive).  Then y[:, :, 4i, 4j] = x + RRDB(x) + 8 exactly, and with a
+    loss that weights only those pixels by the golden R, the gradient arriving at the RRDB output is exactly R: identity convs, nearest
+    upsampling and unit-slope activations move gradients without arithmetic."""
+    g = golden('g_c_rrdb')
+    cfg = dict(num_in_ch=64, num_out_ch=64, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
+    net = ira.build_network(dict(type='RRDBNet', **cfg)).to(cuda).train()
+    sd = {k: torch.zeros_like(v) for k, v in net.state_dict().items()}
+    eye = torch.zeros(64, 64, 3, 3)
+    eye[torch.arange(64), torch.arange(64), 1, 1] = 1.0
+    for name in ('conv_first', 'conv_body', 'conv_up1', 'conv_up2', 'conv_hr', 'conv_last'):
+        sd[f'{name}.weight'] = eye.clone()
+    sd['conv_up1.bias'] = torch.full((64,), 8.0)
+    for k, v in synth.rrdb_state_dict(21, 64, 32).items():
+        sd[f'body.0.{k}'] = torch.from_numpy(v)
+    net.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(g['x']).to(cuda).requires_grad_(True)
+    y = net(x)
+    assert y.shape == (1, 64, 32, 32)
+    out = y[:, :, ::4, ::4] - 8.0 - x.detach()             # = RRDB(x) (the trunk adds the skip x, the head the bias)
+    assert float((out.cpu() - torch.from_numpy(g['out'])).abs().max()) < 5e-6
+    weight = torch.zeros_like(y)
+    weight[:, :, ::4, ::4] = torch.from_numpy(g['R']).to(cuda)
+    (y * weight).sum().backward()
+    gx = x.grad.cpu().numpy() - g['R']                      # minus the skip path's share
+    assert _rel(gx, g['grad_x']) < 1e-4
+    named = dict(net.named_parameters())
+    rrdb_names = [n for n in named if n.startswith('body.0.')]
+    norms = np.array([float(named[n].grad.double().norm()) for n in rrdb_names])
+    assert len(norms) == 30 and np.abs(norms - g['grad_norms']).max() <= 1e-4 * g['grad_norms'].max()
+    assert _rel(named['body.0.rdb3.conv5.weight'].grad, g['grad_rdb3_conv5_weight']) < 1e-4
+    assert _rel(named['body.0.rdb1.conv1.weight'].grad, g['grad_rdb1_conv1_weight']) < 1e-4
+    assert _rel(named['body.0.rdb2.conv3.bias'].grad, g['grad_rdb2_conv3_bias']) < 1e-4

@@ -263,27 +263,40 @@ def test_inference_script_sharded_over_two_processes(cuda, tmp_path):
 
 
 def test_bench_line_contract(cuda):
-    """bench.py prints exactly one JSON line with the driver's fields, the roofline object of the dominant kernel and the CPU
-    baseline (checked on a short run)."""
+    """bench.py prints exactly one JSON line with the driver's fields, the roofline object of the dominant kernel, the CPU baseline and
+    the secondary workloads (BASELINE configs 3 and 5, each with its own roofline) — checked on a short run."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1'], capture_output=True, text=True,
-                       timeout=600, cwd=root)
+                       timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-              'data', 'config', 'roofline', 'cpu_baseline'):
+              'data', 'config', 'roofline', 'cpu_baseline', 'secondary'):
         assert k in d, k
     assert d['unit'] == 'images/sec' and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
     assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
     assert 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - 16 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 0.05 * d['value']
-    rf = d['roofline']
-    assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
-    assert 0.5 < rf['frac'] < 1.0 and (rf['traffic'] is None or rf['traffic'] > 1e8)
+
+    def check_roofline(rf):
+        assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+        assert 0.05 < rf['frac'] < 1.0 and (rf['traffic'] is None or rf['traffic'] > 1e6) and 'stored' in rf['traffic_source']
+    check_roofline(d['roofline'])
+    assert d['roofline']['frac'] > 0.5
     cb = d['cpu_baseline']
-    assert cb['kind'] in ('port', 'reference') and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'images/sec' and cb['sample']
+    assert cb['kind'] in ('port', 'reference') and cb['cores'] >= 1 and cb['value'] >= cb['median'] > 0 and cb['unit'] == 'images/sec'
+    assert cb['sample'] and sum(len(v) for v in cb['all_rates'].values()) >= 3
+    sec = d['secondary']
+    assert set(sec) == {'c3_train_step', 'c5_tiled_4k_bf16', 'c5_tiled_4k_fp32'} and not any('error' in v for v in sec.values()), sec
+    c3 = sec['c3_train_step']
+    assert c3['unit'] == 'images/sec' and c3['config']['global_batch'] == 32 and 'UNetDiscriminatorSN' in c3['metric'] and c3['value'] > 50
+    assert all(np.isfinite(v) for v in c3['losses'].values())
+    check_roofline(c3['roofline'])
+    for key in ('c5_tiled_4k_bf16', 'c5_tiled_4k_fp32'):
+        assert sec[key]['unit'] == 'frames/sec' and sec[key]['scaling'] == 'strong' and sec[key]['value'] > 0.1
+    check_roofline(sec['c5_tiled_4k_bf16']['roofline'])

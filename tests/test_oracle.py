@@ -35,9 +35,20 @@ def test_rdb_backward(golden):
 
 
 def test_rrdb(golden):
+    """G-c: forward AND backward of the oracle's RRDB against the reference's (input gradient, parameter-gradient norms, three full
+    gradients) — autograd through the restatement must reproduce autograd through the reference's module."""
     g = golden('g_c_rrdb')
-    sd = synth.rrdb_state_dict(21, 64, 32)
-    _close(R.rrdb_forward(torch.from_numpy(g['x']), sd), g['out'])
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in synth.rrdb_state_dict(21, 64, 32).items()}
+    x = torch.from_numpy(g['x']).clone().requires_grad_(True)
+    out = R.rrdb_forward(x, sd)
+    _close(out.detach(), g['out'])
+    (out * torch.from_numpy(g['R'])).sum().backward()
+    _close(x.grad, g['grad_x'], 2e-6 * float(np.abs(g['grad_x']).max()) + 1e-7)
+    norms = np.array([float(v.grad.double().norm()) for v in sd.values()])
+    assert np.abs(norms - g['grad_norms']).max() <= 1e-5 * g['grad_norms'].max()
+    for key, name in (('grad_rdb3_conv5_weight', 'rdb3.conv5.weight'), ('grad_rdb1_conv1_weight', 'rdb1.conv1.weight'),
+                      ('grad_rdb2_conv3_bias', 'rdb2.conv3.bias')):
+        _close(sd[name].grad, g[key], 2e-6 * float(np.abs(g[key]).max()) + 1e-7)
 
 
 def test_config1_full_network(golden):
