@@ -130,24 +130,26 @@ def kernel_rooflines(net, x, peak_tflops=PEAK_F32_TFLOPS):
     return profile_launches(one_forward, peak_tflops)
 
 
-def stored_counters(kernel):
+def stored_counters(kernel, suffix=''):
     """HBM traffic and MFMA-busy of ``kernel`` from the committed rocprofv3 --pmc passes (NOT measured in this run: they need the
-    profiler).  Returns (traffic bytes per launch | None, mfma busy | None, provenance string)."""
+    profiler).  ``suffix`` '_c3' selects the tables of the C3 training step (same kernels, other launch sizes).  Returns (traffic
+    bytes per launch | None, mfma busy | None, provenance string)."""
     traffic = mfma = None
-    tpath, upath = os.path.join(ROOT, 'profiles', 'traffic.json'), os.path.join(ROOT, 'profiles', 'mfma_util.json')
+    tpath = os.path.join(ROOT, 'profiles', f'traffic{suffix}.json')
+    upath = os.path.join(ROOT, 'profiles', f'mfma_util{suffix}.json')
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(kernel)
     if os.path.exists(upath):
         mfma = (json.load(open(upath)).get(kernel) or {}).get('mfma_util')
-    src = 'stored: profiles/traffic.json + profiles/mfma_util.json (separate rocprofv3 --pmc passes of this bench, tools/profile_round.sh; ' \
+    src = f'stored: profiles/traffic{suffix}.json + profiles/mfma_util{suffix}.json (separate rocprofv3 --pmc passes of this bench, tools/profile_round.sh; ' \
           'FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction); null = no stored counter for this kernel'
     return traffic, mfma, src
 
 
-def roofline_of(ks, peak_tflops):
+def roofline_of(ks, peak_tflops, suffix=''):
     """The roofline object of a workload from its kernel table: dominant kernel, binding roof = the one it sits closer to."""
     k0 = ks[0]
-    traffic, mfma_pmc, src = stored_counters(k0['kernel'])
+    traffic, mfma_pmc, src = stored_counters(k0['kernel'], suffix)
     mfma_frac, hbm_frac = k0['tflops'] / peak_tflops, k0['hbm_frac']
     common = {'traffic': traffic, 'traffic_source': src, 'kernel': k0['kernel'], 'avg_launch_ms': k0['avg_ms'],
               'launches': k0['launches'], 'share_of_profiled_time': round(k0['total_ms'] / sum(k['total_ms'] for k in ks), 4),
@@ -226,7 +228,7 @@ def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dty
         peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
         ks = profile_launches(lambda: step(warmup + steps + 1), peak)
         torch.cuda.synchronize()
-        res['roofline'] = roofline_of(ks, peak)
+        res['roofline'] = roofline_of(ks, peak, '_c3' if (disc == 'unet' and batch == 32 and lq == 128) else '_none')
         res['kernels'] = ks[:6]
     del model
     torch.cuda.empty_cache()
@@ -272,7 +274,7 @@ def measure_tiled(net, world, rank, dev, dist, backend, *, dtype, steps, warmup,
         quarter = img[:, :, :1024, :1024 * tile_batch // 2].contiguous()  # tile_batch whole 512x512 cells: the frame's launch shapes
         ks = profile_launches(lambda: tiled_forward(net, quarter, tile=512, pad=16, scale=4, max_batch=tile_batch, out_dtype=torch.uint8), peak)
         torch.cuda.synchronize()
-        res['roofline'] = roofline_of(ks, peak)
+        res['roofline'] = roofline_of(ks, peak, '_tiled')  # no stored counters at the tiler's launch sizes: traffic null
         res['roofline']['note'] = 'kernel table from a %dx%d corner of the frame (%d full cells per forward, the launch shapes of the frame)' \
             % (quarter.shape[2], quarter.shape[3], tile_batch)
     del out

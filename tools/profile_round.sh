@@ -1,21 +1,48 @@
-# bf16 traces run with --groups 1: per-kernel durations are only meaningful when launches do not overlap (the default
-# bf16 forward runs image groups on concurrent streams)
+# Round profile pass (on the GPU box): rocprofv3 kernel statistics of the bench commands and, in separate --pmc passes (no trace
+# domains besides the kernel trace), HBM traffic, MFMA-busy and the SQ wave-state counters.  usage: bash tools/profile_round.sh r02
+# bf16 traces run with --groups 1: per-kernel durations are only meaningful when launches do not overlap.
 set -e
 R=$GRAFT_REPO_ROOT
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O $R/profiles
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01b_fp32 -- python3 $R/bench.py --no-cpu-baseline --steps 10 > $R/gpurun_out/r01b_fp32.log 2>&1
-echo fp32 trace done
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01b_bf16 -- python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --steps 10 > $R/gpurun_out/r01b_bf16.log 2>&1
-echo bf16 trace done
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r01b_pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/r01b_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r01b_pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/r01b_pmc_write.log 2>&1
-echo fp32 pmc done
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r01b_pmc_fetch16 -- python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/r01b_pmc_fetch16.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r01b_pmc_write16 -- python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/r01b_pmc_write16.log 2>&1
-echo bf16 pmc done
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01b_train_bf16 -- python3 $R/tools/perf_train.py 16 bf16 > $R/gpurun_out/r01b_train_bf16.log 2>&1
-echo train bf16 done
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01b_train_fp32 -- python3 $R/tools/perf_train.py 16 fp32 > $R/gpurun_out/r01b_train_fp32.log 2>&1
-echo train fp32 done
+S=$R/tools/rocpd_summary.py
+db() { find $1 -name "*_results.db" | head -1; }
+run() { name=$1; shift; rocprofv3 "$@" > $O/$name.log 2>&1 || { echo "FAILED $name"; tail -5 $O/$name.log; exit 1; }; echo "$name done"; }
+
+# 1. kernel statistics
+run ks_default --kernel-trace --stats -d $O/ks_default -- python3 $R/bench.py --no-cpu-baseline
+run ks_fp32 --kernel-trace --stats -d $O/ks_fp32 -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 10
+run ks_bf16 --kernel-trace --stats -d $O/ks_bf16 -- python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --no-secondary --steps 10
+run ks_c3 --kernel-trace --stats -d $O/ks_c3 -- python3 $R/bench.py --mode train --dtype bf16 --disc unet --lq 128 --batch 32 --steps 3 --warmup 1
+python3 $S stats $(db $O/ks_default) $R/profiles/${TAG}_bench_default_kernel_stats.csv > $O/ks_default.txt
+python3 $S stats $(db $O/ks_fp32) $R/profiles/${TAG}_fp32_kernel_stats.csv > $O/ks_fp32.txt
+python3 $S stats $(db $O/ks_bf16) $R/profiles/${TAG}_bf16_kernel_stats.csv > $O/ks_bf16.txt
+python3 $S stats $(db $O/ks_c3) $R/profiles/${TAG}_c3_train_bf16_unet_kernel_stats.csv > $O/ks_c3.txt
+head -6 $O/ks_fp32.txt $O/ks_bf16.txt $O/ks_c3.txt
+
+# 2. HBM traffic (FETCH_SIZE and WRITE_SIZE cannot share a pass) and MFMA busy
+B32="python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 1"
+B16="python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --no-secondary --steps 2 --warmup 1"
+C3="python3 $R/bench.py --mode train --dtype bf16 --disc unet --lq 128 --batch 32 --steps 1 --warmup 1"
+for w in f32:"$B32" b16:"$B16" c3:"$C3"; do
+  k=${w%%:*}; cmd=${w#*:}
+  run fetch_$k --pmc FETCH_SIZE -d $O/fetch_$k -- $cmd
+  run write_$k --pmc WRITE_SIZE -d $O/write_$k -- $cmd
+  run mfma_$k --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/mfma_$k -- $cmd
+  run gui_$k --pmc GRBM_GUI_ACTIVE -d $O/gui_$k -- $cmd
+done
+# per-workload tables: the C3 step runs the same kernels at other sizes, so its dispatches must not be averaged into the inference rows
+python3 $S traffic $R/profiles/traffic.json $(db $O/fetch_f32) $(db $O/write_f32) $(db $O/fetch_b16) $(db $O/write_b16) > $O/traffic.txt
+python3 $S traffic $R/profiles/traffic_c3.json $(db $O/fetch_c3) $(db $O/write_c3) > $O/traffic_c3.txt
+python3 $S mfma $R/profiles/mfma_util.json $(db $O/mfma_f32) $(db $O/gui_f32) $(db $O/mfma_b16) $(db $O/gui_b16) > $O/mfma.txt
+python3 $S mfma $R/profiles/mfma_util_c3.json $(db $O/mfma_c3) $(db $O/gui_c3) > $O/mfma_c3.txt
+for f in traffic traffic_c3 mfma_util mfma_util_c3; do cp $R/profiles/$f.json $R/profiles/${TAG}_$f.json; done
+
+# 3. wave-state counters of the inference kernels
+bash $R/tools/pmc_sq.sh fp32 ${TAG}_fp32 > $O/sq_fp32.log 2>&1 && cp $R/gpurun_out/pmc_sq_${TAG}_fp32.txt $R/profiles/${TAG}_pmc_sq_fp32.txt
+bash $R/tools/pmc_sq.sh bf16 ${TAG}_bf16 > $O/sq_bf16.log 2>&1 && cp $R/gpurun_out/pmc_sq_${TAG}_bf16.txt $R/profiles/${TAG}_pmc_sq_bf16.txt
+find $R/gpurun_out -name "*_results.db" -size +8M -delete
 find $R/gpurun_out -name "*kernel_trace.csv" -delete
-du -sh $R/gpurun_out
+du -sh $R/gpurun_out $R/profiles
