@@ -322,7 +322,7 @@ def main():
     ap.add_argument('--lq', type=int, default=32, help='--mode train: LR patch size (gt = 4x)')
     ap.add_argument('--disc', choices=('vgg', 'unet'), default='vgg', help='--mode train: discriminator')
     ap.add_argument('--disc-dtype', choices=('fp32', 'bf16'), default=None, help='--mode train: discriminator arithmetic (default: --dtype)')
-    ap.add_argument('--chain', action='store_true', help='tuning: dense blocks as one persistent chain launch each (sr_set_conv_chain*)')
+    ap.add_argument('--chain', type=int, default=0, help='tuning: dense blocks as one persistent chain launch each (sr_set_conv_chain*): 1 = 32-row tiles, 2 = 16-row tiles (bf16)')
     ap.add_argument('--tall64', action='store_true', help='tuning: fp32 64-cout convs on 16-row tiles (development switch)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C3 training step and the C5 tiled frame next to the headline')
     ap.add_argument('--secondary-timeout', type=float, default=300.0)
@@ -355,7 +355,7 @@ def main():
         _lib.load().sr_dev_set_f32_tall64(1)
     if args.chain:
         from image_restoration_amd import _lib
-        _lib.check(_lib.load().sr_set_conv_chain(1), 'sr_set_conv_chain')
+        _lib.check(_lib.load().sr_set_conv_chain(args.chain), 'sr_set_conv_chain')
         _lib.check(_lib.load().sr_set_conv_chain_f32(1), 'sr_set_conv_chain_f32')
     def finish(line):
         if rank == 0:

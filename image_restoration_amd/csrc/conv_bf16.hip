@@ -555,7 +555,8 @@ struct ChainParams {
 
 __device__ __forceinline__ int flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(512) void conv_chain_bf16_kernel(const ChainParams P) {
+template <bool TALL>
+__global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(const ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_item;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -610,10 +611,17 @@ __global__ __launch_bounds__(512) void conv_chain_bf16_kernel(const ChainParams 
     t /= P.tiles_x;
     const int ty = t % P.tiles_y, n = t / P.tiles_y;
     long long tk[4] = {0, 0, 0, 0};
-    if (P.cot[k] == 2)
-      conv_tile32_h<2, true>(P.lv[k], tx, ty, n, smem, P.dbg ? tk : nullptr);
-    else
-      conv_tile32_h<1, true>(P.lv[k], tx, ty, n, smem, P.dbg ? tk : nullptr);
+    if constexpr (TALL) {
+      if (P.cot[k] == 2)
+        conv_tile32_h<2, true>(P.lv[k], tx, ty, n, smem, P.dbg ? tk : nullptr);
+      else
+        conv_tile32_h<1, true>(P.lv[k], tx, ty, n, smem, P.dbg ? tk : nullptr);
+    } else {
+      if (P.cot[k] == 2)
+        conv_tile_h<2, 2, 8, false, false, true>(P.lv[k], 0, tx, ty, n, smem);
+      else
+        conv_tile_h<1, 2, 8, false, false, true>(P.lv[k], 0, tx, ty, n, smem);
+    }
     if (P.dbg) c4 = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
     __syncthreads();                                   // ... and every other wave's; s_item may be rewritten
@@ -725,15 +733,16 @@ extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
   return 1 + SR_CHAIN_EPOCHS + (size_t)n * sr::cdiv(h, 16) * sr::cdiv(w, 32);
 }
 
-// Off by default: measured in the network (BASELINE config 2, batch 16, same box) the chain launch is within +-2.6 % of the
-// conv-by-conv path in bf16 (1402 vs 1439 img/s) — what it saves in launch gaps it pays in hand-offs.  sr_set_conv_chain(1)
-// turns it on; tests/test_chain_bf16_gpu.py keeps it bit-exact against the per-conv kernels.
-static bool g_chain_enabled = false;
+// Default: 16-row tiles, two workgroups per CU (mode 2).  Same box, BASELINE config 2 in bf16 (batch 16, 20 steps): conv by conv
+// 1502 img/s, mode 2 1541, mode 1 (32-row ring tiles, one workgroup per CU) 1458; a dense block alone 159 -> 147 us at batch 16,
+// 310 -> 272 us at batch 32, 771 -> 664 us on four 544x544 tiler cells.  With two workgroups per CU one's hand-off, prologue and
+// epilogue overlap the other's MFMA loop; the single 32-row workgroup has nothing to overlap them with.
+static int g_chain_enabled = 2;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU)
 static long long* g_chain_clocks = nullptr;
 // Development aid (tools/chain_phase.py; not part of the ABI): per work item, wave 0 writes claim / wait / acquire / tile / drain clocks.
 extern "C" void sr_dev_chain_phase_clocks(void* buf) { g_chain_clocks = (long long*)buf; }
 extern "C" int sr_set_conv_chain(int enabled) {
-  g_chain_enabled = enabled != 0;
+  g_chain_enabled = enabled;
   return SR_OK;
 }
 
@@ -742,15 +751,17 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
   SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
   // eligibility of the one-launch form: one tile grid (same n, H, W, no upsampling), CB16 outputs, <= 64 couts, 16-row tiles,
   // enough tiles to fill the chip; anything else runs conv by conv (same results)
+  const bool tall = g_chain_enabled != 2;
+  const int rows = tall ? 32 : 16;
   bool one_launch = g_chain_enabled && sync && nconv >= 2 && nconv <= SR_CHAIN_MAX && call_index >= 0 && call_index < SR_CHAIN_EPOCHS &&
                     !sr::prof_on();
   for (int k = 0; k < nconv && one_launch; ++k) {
     const sr_conv3x3_desc& c = d[k];
     one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 &&
-                 c.cout <= 64 && c.cin_pad <= 256 && c.in_h % 32 == 0;
+                 c.cout <= 64 && c.cin_pad <= 256 && c.in_h % rows == 0;
   }
   const int conc = sr::launch_concurrency();
-  if (one_launch) one_launch = (long long)sr::cdiv(d[0].in_w, 32) * (d[0].in_h / 32) * d[0].n * conc >= 192;
+  if (one_launch) one_launch = (long long)sr::cdiv(d[0].in_w, 32) * (d[0].in_h / rows) * d[0].n * conc >= (tall ? 192 : 384);
   if (!one_launch) {
     for (int k = 0; k < nconv; ++k)
       if (int rc = sr_conv3x3_bf16(&d[k], stream_)) return rc;
@@ -761,7 +772,7 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
     if (int rc = fill_params_h(&d[k], P.lv[k], "sr_conv3x3_chain_bf16")) return rc;
     P.cot[k] = ((d[k].cout + 31) / 32 * 32) % 64 == 0 ? 2 : 1;
     P.lv[k].tiles_x = sr::cdiv(P.lv[k].W, 32);
-    P.lv[k].tiles_y = P.lv[k].H / 32;
+    P.lv[k].tiles_y = P.lv[k].H / rows;
     P.lv[k].cogs = 1;
   }
   P.nconv = nconv;
@@ -773,21 +784,22 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
   P.done = sync + 1 + SR_CHAIN_EPOCHS;
   P.epoch = call_index * 8;
   P.dbg = g_chain_clocks;
-  constexpr int lds = T32_LDS;
-  auto kern = conv_chain_bf16_kernel;
+  const int lds = tall ? T32_LDS : conv_bf16_lds<2, 2, 8>();
+  auto kern = tall ? conv_chain_bf16_kernel<true> : conv_chain_bf16_kernel<false>;
   if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;
-  // Grid = what the chip holds at once (one workgroup per CU by LDS), shared between concurrently launching image groups.  Not a
-  // correctness condition (work items are claimed, see the kernel): more would only queue, fewer would idle CUs.
-  static int slots[16] = {0};
+  // Grid = what the chip holds at once (one 32-row or two 16-row workgroups per CU by LDS), shared between concurrently launching
+  // image groups.  Not a correctness condition (work items are claimed, see the kernel): more would only queue, fewer would idle CUs.
+  static int slots[2][16] = {{0}, {0}};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  if (slots[dev] == 0) {
+  if (slots[tall][dev] == 0) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    slots[dev] = (per_cu > 1 ? 1 : per_cu) * cus;
+    const int want = tall ? 1 : 2;
+    slots[tall][dev] = (per_cu > want ? want : per_cu) * cus;
   }
-  long long grid = slots[dev] / (conc > 1 ? conc : 1);
+  long long grid = slots[tall][dev] / (conc > 1 ? conc : 1);
   if (grid > P.ntiles) grid = P.ntiles;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, P);

@@ -14,12 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def chain_on():
-    """The chain launch is opt-in (sr_set_conv_chain*): on for these tests, restored afterwards."""
-    lib = _lib.load()
-    _lib.check(lib.sr_set_conv_chain(1), 'sr_set_conv_chain')
+def chain_restore():
+    """Both tile geometries of the chain launch (sr_set_conv_chain 1: 32-row ring tiles, 2: 16-row tiles, the default)."""
     yield
-    _lib.check(lib.sr_set_conv_chain(0), 'sr_set_conv_chain')
+    _lib.check(_lib.load().sr_set_conv_chain(2), 'sr_set_conv_chain')
 
 
 def _rdb(dev, nf, gc, seed):
@@ -61,7 +59,9 @@ def _fresh(dev, n, nf, gc, h, w, seed):
     (2, 64, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
     (12, 120, 128, 64, 32),    # height not a multiple of 32: fallback
 ])
-def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc):
+@pytest.mark.parametrize('mode', [1, 2])
+def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
+    _lib.check(_lib.load().sr_set_conv_chain(mode), 'sr_set_conv_chain')
     packs = _rdb(cuda, nf, gc, 3)
     cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
     cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
@@ -79,9 +79,11 @@ def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc):
     assert bool(torch.isfinite(nxt_b.buf[:, :nf // 16].float()).all())
 
 
-def test_chain_under_uneven_load_and_with_rrdb_residuals(cuda):
+@pytest.mark.parametrize('mode', [1, 2])
+def test_chain_under_uneven_load_and_with_rrdb_residuals(cuda, mode):
     """Three chained dense blocks = one RRDB (the third closes with the RRDB residual, rrdbnet_arch.py:58-63) while a second stream
     keeps part of the chip busy with unrelated bandwidth-heavy work: hand-offs must hold when workgroups are delayed unevenly."""
+    _lib.check(_lib.load().sr_set_conv_chain(mode), 'sr_set_conv_chain')
     n, h, w, nf, gc = 16, 128, 128, 64, 32
     packs = [_rdb(cuda, nf, gc, 10 + r) for r in range(3)]
 

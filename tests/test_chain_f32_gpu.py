@@ -122,10 +122,11 @@ def test_network_forward_is_identical_with_and_without_chain_launches(cuda):
         net.set_compute_dtype(dtype)
         with torch.no_grad():
             try:
-                _lib.check(switch(1), 'switch')
+                _lib.check(switch(2 if dtype == 'bf16' else 1), 'switch')
                 y_chain = net(x).clone()
-            finally:
                 _lib.check(switch(0), 'switch')
-            y_plain = net(x).clone()
+                y_plain = net(x).clone()
+            finally:
+                _lib.check(switch(2 if dtype == 'bf16' else 0), 'switch')
         assert torch.equal(y_chain, y_plain), dtype
         assert bool(torch.isfinite(y_chain).all())

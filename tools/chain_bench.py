@@ -77,8 +77,14 @@ def bench_f32(n, h, w, iters=10, nf=64, gc=32):
 
 
 if __name__ == '__main__':
-    bench_f32(16, 128, 128)
-    bench_f32(32, 128, 128)
+    from image_restoration_amd import _lib
+    mode = int(os.environ.get('CHAIN_MODE', '1'))
+    _lib.check(_lib.load().sr_set_conv_chain(mode), 'chain')
+    _lib.check(_lib.load().sr_set_conv_chain_f32(1), 'chain')
+    print('bf16 chain mode', mode)
+    if os.environ.get('CHAIN_F32'):
+        bench_f32(16, 128, 128)
+        bench_f32(32, 128, 128)
     bench(16, 128, 128)
     bench(4, 128, 128)
     bench(32, 128, 128)
