@@ -225,7 +225,8 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
  * order and wait for conv k-1 on the 3x3 tile neighbourhood (write-through stores + agent-scope flags), so ramp-up, tail and the
  * kernel boundary are paid once per chain.  Results are bit-identical to calling sr_conv3x3_bf16 conv by conv, which is also what
  * the entry point does when the chain is not eligible (upsampling, NCHW output, > 64 couts, ragged height, small launches,
- * profiling) or when disabled with sr_set_conv_chain(0).
+ * profiling) or when disabled.  sr_set_conv_chain(mode): 0 = off, 1 = 32-row ring tiles on one workgroup per CU, 2 = 16-row
+ * tiles on two workgroups per CU (default: the faster one in the network, see conv_bf16.hip).
  *   sync        device int32[sr_conv3x3_chain_sync_ints(n, h, w)], zeroed by the caller (hipMemsetAsync) before the first call that
  *               uses it; calls sharing a block pass increasing call_index 0, 1, 2, ... < 256 and the same n / h / w
  *   sync[0]     is raised by the kernel if a wait on a dependency timed out (bounded spins: never a hang) */
