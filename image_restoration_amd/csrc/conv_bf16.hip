@@ -385,6 +385,124 @@ __global__ __launch_bounds__(NW * 64) void conv_bf16_kernel(const ConvParamsH p)
   conv_tile_h<COT, PT, NW, NCHW_OUT, S2, false>(p, cog, tx, ty, n, smem);
 }
 
+// ------------------------------------------------------------------------------------------------ few couts
+// conv_last (Cout = 3, rrdbnet_arch.py:118) and the U-Net discriminator's logit conv (Cout = 1): on the 32-cout tile 29-31 of 32
+// MFMA rows multiply zero weights (203 us per batch of 16 512x512 images).  Here one v_mfma_f32_4x4x4_16B_bf16 serves 64 pixels x
+// 4 couts x 4 channels: lane = pixel (two tile rows of 32 pixels per wave instruction), its B operand 8 bytes of its own pixel,
+// its A operand the 8 bytes of cout (lane & 3) — the twin of conv_fewcout_f32_kernel.  The weights come out of the ordinary
+// 32-cout image (rows 0..3 of each tap), so nothing is packed differently.  HBM-bound: 32 B read per pixel and chunk, 4 B written
+// per pixel and cout.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void conv_fewcout_bf16_kernel(const ConvParamsH p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TH = 16, XROW = 34, XPIX = (TH + 2) * XROW;
+  constexpr int XBYTES = ((XPIX * 32 + 1023) / 1024) * 1024, NXU = XBYTES / 1024;
+  constexpr int WBYTES = 2048, STAGE = XBYTES + WBYTES;  // 9 taps x 4 couts x 32 B = 1152 B
+  constexpr int NXR = (NXU + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH;
+  const long long plane_b = (long long)p.in_h * p.in_w * 32;
+  const char* in_n = p.in + (long long)n * p.in_nb;
+
+  int xoff[NXR];
+#pragma unroll
+  for (int r = 0; r < NXR; ++r) {
+    const int q = (r * 4 + wave) * 64 + lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool valid = (pix < XPIX) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    xoff[r] = valid ? (((gy >> p.src_shift) * p.in_w + (gx >> p.src_shift)) * 32 + half * 16) : -1;
+  }
+  // weight piece q of the chunk: tap = q / 8, cout = (q % 8) / 2, half = q % 2  ->  packed image [tap][32 couts][32 B]
+  const int wq = wave * 64 + lane;
+  const int woff = (wave < 2 && wq < 72) ? ((wq >> 3) * 32 + ((wq & 7) >> 1)) * 32 + (wq & 1) * 16 : -1;
+
+  auto stage = [&](int buf, int cb) {
+    char* xs = smem + buf * STAGE;
+    const char* plane = in_n + (size_t)cb * plane_b;
+#pragma unroll
+    for (int r = 0; r < NXR; ++r) {
+      const int u = r * 4 + wave;
+      if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : p.zero, xs + u * 1024);
+    }
+    if (wave < 2) {  // 72 pieces of 16 B
+      const char* wchunk = p.w + (size_t)cb * (9 * 32 * 32);
+      glds16h(woff >= 0 ? (const void*)(wchunk + woff) : p.zero, xs + XBYTES + wave * 1024);
+    }
+  };
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int prow = lane >> 5, pcol = lane & 31;
+  const int xlane = ((wave * 4 + prow) * XROW + pcol) * 32;  // this lane's pixel, row group 0, tap (0, 0)
+  const int wlane = (lane & 3) * 32;                         // this lane's cout row of the weight chunk
+
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * STAGE + xlane;
+    const char* ws = smem + buf * STAGE + XBYTES + wlane;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int tap = dy * 3 + dx;
+        const bf16x8 w0 = *(const bf16x8*)(ws + tap * 128), w1 = *(const bf16x8*)(ws + tap * 128 + 16);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const char* xp = xs + ((2 * g + dy) * XROW + dx) * 32;
+          const bf16x8 a0 = *(const bf16x8*)xp, a1 = *(const bf16x8*)(xp + 16);
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 W0 = __builtin_bit_cast(s16x8, w0), W1 = __builtin_bit_cast(s16x8, w1);
+          const s16x8 A0 = __builtin_bit_cast(s16x8, a0), A1 = __builtin_bit_cast(s16x8, a1);
+          acc[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(s16x4{W0[0], W0[1], W0[2], W0[3]}, s16x4{A0[0], A0[1], A0[2], A0[3]}, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(s16x4{W0[4], W0[5], W0[6], W0[7]}, s16x4{A0[4], A0[5], A0[6], A0[7]}, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(s16x4{W1[0], W1[1], W1[2], W1[3]}, s16x4{A1[0], A1[1], A1[2], A1[3]}, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(s16x4{W1[4], W1[5], W1[6], W1[7]}, s16x4{A1[4], A1[5], A1[6], A1[7]}, acc[g], 0, 0, 0);
+        }
+      }
+  };
+
+  const int nchunk = p.cin_blocks;
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
+    compute(c & 1);
+    __syncthreads();
+  }
+  // epilogue: bias, LeakyReLU, scale; NCHW fp32 store (lane = pixel: 32 consecutive x per row and channel)
+  const long long HW = (long long)p.H * p.W;
+  const int x = x0 + pcol;
+  float bias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bias[e] = (p.bias && e < p.cout) ? p.bias[e] : 0.f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int y = y0 + wave * 4 + 2 * g + prow;
+    if (y >= p.H || x >= p.W) continue;
+    float* o = (float*)(p.out + (long long)n * p.out_nb) + (long long)y * p.W + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e >= p.cout) break;
+      float v = acc[g][e] + bias[e];
+      v = v > 0.f ? v : v * p.slope;
+      o[e * HW] = v * p.alpha;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ 32x32 ring tile
 // The chain kernel's tile: 32 rows x 32 columns x 32*COT couts on ONE 8-wave workgroup per CU (two waves per SIMD, 4 rows a wave).
 // What differs from conv_tile_h, and why (measured on the 16-row two-workgroups-per-CU form, tools/chain_phase.py and the ISA):
@@ -820,6 +938,31 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   const bool w8 = p.H % 32 == 0;  // whole 32-row tiles for the 8-wave x 4-row workgroup
   if (d->out_nchw) {
     if (p.out_nb == 0) p.out_nb = (long long)d->cout * p.H * p.W * 4;
+    if (d->cout <= 4 && !d->res1 && !d->res2 && !d->mask_src) {  // conv_last / logit conv: the 4-cout kernel (16-row tiles)
+      constexpr int lds = 2 * (((18 * 34 * 32 + 1023) / 1024) * 1024 + 2048);
+      auto kern = conv_fewcout_bf16_kernel;
+      if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;
+      p.tiles_x = sr::cdiv(p.W, 32);
+      p.tiles_y = sr::cdiv(p.H, 16);
+      const bool prof = sr::prof_on();
+      if (prof) {
+        sr_launch_record r = {};
+        r.kernel_id = 50;
+        r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
+        r.cout = d->cout;
+        r.n = d->n;
+        r.h = p.H;
+        r.w = p.W;
+        const double px = (double)d->n * p.H * p.W;
+        r.flops = 2.0 * 9 * r.cin * r.cout * px;
+        r.bytes = (double)d->n * p.in_h * p.in_w * r.cin * 2.0 + px * r.cout * 4.0;
+        sr::prof_begin(stream, r);
+      }
+      hipLaunchKernelGGL(kern, dim3(p.tiles_x * p.tiles_y * d->n), dim3(256), lds, stream, p);
+      if (prof) sr::prof_end(stream);
+      SR_CHECK_LAUNCH("conv_fewcout_bf16 launch");
+      return SR_OK;
+    }
     if (gc == 64) return w8 ? launch_h<2, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, true>(p, d->n, groups, stream, d);
     return w8 ? launch_h<1, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, true>(p, d->n, groups, stream, d);
   }

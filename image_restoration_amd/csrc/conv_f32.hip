@@ -941,6 +941,7 @@ extern "C" const char* sr_kernel_name(int id) {
     return snames[id - 44];
   }
   if (id == 40) return "wgrad_rdb_bf16_kernel";
+  if (id == 50) return "conv_fewcout_bf16_kernel";
   if (id == 42) return "conv_bf16_kernelILi1ELi1ELi4ELb0E";
   if (id == 43) return "conv_bf16_kernelILi2ELi1ELi4ELb0E";
   if (id == 15) return "conv_f32_kernelILi1ELi1ELi3ELb0E";

@@ -362,3 +362,27 @@ def test_bf16_gradients_equal_a_float64_model_of_bf16_storage(cfg, shape):
     assert rel(y.detach(), yr.detach()) < 1e-3
     errs = sorted([rel(x.grad, xr.grad)] + [rel(p.grad, sd[k].grad) for k, p in net.named_parameters()])
     assert errs[-1] < 3e-2 and errs[len(errs) // 2] < 1.5e-2, (errs[-1], errs[len(errs) // 2])
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,ups', [(2, 64, 3, 48, 64, False), (3, 64, 1, 33, 70, False), (2, 32, 4, 16, 32, False),
+                                                (1, 64, 3, 20, 24, True), (2, 128, 2, 17, 31, False)])
+def test_few_cout_conv_bf16_matches_float64_of_rounded_operands(n, cin, cout, h, w, ups):
+    """conv_last (3 couts) / the U-Net discriminator's logit conv (1 cout) with an fp32 NCHW destination run on the 4-cout kernel
+    (v_mfma_f32_4x4x4_16B_bf16).  Against a float64 convolution of the SAME bf16-rounded operands: fp32 accumulation order only
+    (2e-5 of the largest output), on whole and ragged tiles, with and without the nearest x2 source map, bias and LeakyReLU."""
+    import torch.nn.functional as F
+    from image_restoration_amd import hip_ops as H
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g) * 0.1
+    xb, wb = x.to(torch.bfloat16).double(), wt.to(torch.bfloat16).double()
+    src = F.interpolate(xb, scale_factor=2, mode='nearest') if ups else xb
+    ref = F.leaky_relu(F.conv2d(src, wb, b.double(), padding=1), 0.2) * 0.5
+    pc = H.PackedConvBF16(wt.to(dev), b.to(dev))
+    H_, W_ = (2 * h, 2 * w) if ups else (h, w)
+    out = torch.full((n, cout, H_, W_), float('nan'), device=dev)
+    H.conv3x3_bf16(H.nchw_to_cb16(x.to(dev)), pc, out_nchw=out, upsample=ups, act_slope=0.2, alpha=0.5)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, err
