@@ -26,6 +26,9 @@
 #ifndef SR_F32_PIPELINE
 #define SR_F32_PIPELINE 0  // operand reads of tap t+1 issued before the MFMAs of tap t: 216.5 vs 219.0 img/s without (two waves per
 #endif                     // SIMD from different workgroups already cover the LDS latency; the extra registers cost more)
+#ifndef SR_F32_BUFDMA
+#define SR_F32_BUFDMA 1  // LDS-DMA through buffer descriptors (scalar base + 32-bit lane offset) instead of 64-bit flat addresses
+#endif
 #ifndef SR_F32_SWIZZLE
 #define SR_F32_SWIZZLE 1  // LDS bank swizzle of the two 16-byte halves of a pixel / cout (see conv_bf16.hip)
 #endif
@@ -145,6 +148,38 @@ __device__ __forceinline__ void conv_tile_f32(const ConvParams p, const int cog,
     xoff[r] = valid ? (img_off + (sy * p.in_w + sx) * 8 + hsw * 4) : -1;
   }
 
+#if SR_F32_BUFDMA
+  // LDS-DMA through buffer descriptors: base (image / weight image) in scalar registers, a 32-bit per-lane byte offset computed
+  // ONCE per tile, the chunk's offset as the scalar `soffset` — a piece is one instruction with no address arithmetic, against a
+  // 64-bit per-lane address (select zero line / add plane) per piece of the flat form.  Padding lanes carry an offset beyond
+  // num_records: the hardware returns zeros for them.
+  const unsigned x_range = (unsigned)((stacked ? (long long)p.stack_n * p.in_ns : (long long)p.cin_blocks * HWin * 8) * 4);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in_n, 0, x_range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (unsigned)((long long)p.cin_blocks * w_chunk * 4), 0x00020000);
+  unsigned xvo[NXR];
+#pragma unroll
+  for (int r = 0; r < NXR; ++r) xvo[r] = xoff[r] >= 0 ? (unsigned)xoff[r] * 4u : 0xfffffff0u;
+  const unsigned wvo = (SR_F32_SWIZZLE ? (lane ^ ((lane >> 4) & 1)) : lane) * 16;
+  auto stage = [&](int buf, int cb) {
+    char* xs = smem + buf * STAGE;
+    char* ws = xs + XBYTES;
+    const unsigned xso = (unsigned)cb * (unsigned)HWin * 32u, wso = (unsigned)cb * (unsigned)w_chunk * 4u;
+#pragma unroll
+    for (int r = 0; r < NXR; ++r) {
+      const int u = r * NW + wave;
+      if (u < NXU)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (__attribute__((address_space(3))) void*)(xs + u * 1024), 16, xvo[r], xso, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < NWR; ++r) {
+      const int u = r * NW + wave;  // unit = tap * COT + cout sub-tile
+      if (u < NWU)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(ws + u * 1024), 16, wvo,
+                                                 wso + (unsigned)(WT_OUT ? (u / COT) * w_tap + (u % COT) * 256 : u * 256) * 4u, 0, 0);
+    }
+  };
+#else
   auto stage = [&](int buf, int cb) {
     char* xs = smem + buf * STAGE;
     char* ws = xs + XBYTES;
@@ -164,6 +199,8 @@ __device__ __forceinline__ void conv_tile_f32(const ConvParams p, const int cog,
       if (u < NWU) glds16(wsrc + (WT_OUT ? (u / COT) * w_tap + (u % COT) * 256 : u * 256), ws + u * 1024);
     }
   };
+
+#endif
 
   f32x16 acc[COT][PT];
 #pragma unroll
