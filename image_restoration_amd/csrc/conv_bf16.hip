@@ -208,20 +208,32 @@ __device__ __forceinline__ void conv_tile_h(const ConvParamsH p, const int cog, 
     xoff[r] = valid ? ((sy * p.in_w + sx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : -1;  // bank swizzle (header)
   }
 
+  // LDS-DMA through buffer descriptors (see conv_f32.hip): base in scalar registers, one 32-bit per-lane byte offset computed once
+  // per tile, the chunk as the scalar soffset; padding lanes carry an offset beyond num_records and read as zeros.
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)in_n, 0, (unsigned)((long long)p.cin_blocks * plane_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, (unsigned)((long long)p.cin_blocks * WBYTES), 0x00020000);
+  unsigned xvo[NXR];
+#pragma unroll
+  for (int r = 0; r < NXR; ++r) xvo[r] = xoff[r] >= 0 ? (unsigned)xoff[r] : 0xfffffff0u;
+  const unsigned wvo = (lane ^ ((lane >> 4) & 1)) * 16;  // unit (cout i, half) <- half ^ bit3(i)
   auto stage = [&](int buf, int cb) {
     char* xs = smem + buf * STAGE;
     char* ws = xs + XBYTES;
-    const char* plane = in_n + (size_t)cb * plane_b;
+    const unsigned xso = (unsigned)cb * (unsigned)plane_b, wso = (unsigned)cb * (unsigned)WBYTES;
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
       const int u = r * NW + wave;
-      if (u < NXU) glds16h(xoff[r] >= 0 ? (const void*)(plane + xoff[r]) : p.zero, xs + u * 1024);
+      if (u < NXU)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (__attribute__((address_space(3))) void*)(xs + u * 1024), 16, xvo[r], xso, 0, 0);
     }
-    const char* wsrc = wg + (size_t)cb * WBYTES + (lane ^ ((lane >> 4) & 1)) * 16;  // unit (cout i, half) <- half ^ bit3(i)
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
       const int u = r * NW + wave;
-      if (u < NWU) glds16h(wsrc + u * 1024, ws + u * 1024);
+      if (u < NWU)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(ws + u * 1024), 16, wvo,
+                                                 wso + (unsigned)u * 1024u, 0, 0);
     }
   };
 
