@@ -50,6 +50,11 @@ __device__ __forceinline__ void glds16wh(const void* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// LDS-DMA through a buffer descriptor (scalar base, 32-bit lane offset, scalar row offset): see conv_f32.hip.  A descriptor with
+// num_records = 0 delivers zeros without touching memory: rows outside the image and the padding loads of the counted waits.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
 
 // ds_read_b64_tr_b16 through inline asm: behind the builtin hipcc (ROCm 7.2) waits vmcnt(0) before the first LDS read of
 // every step (it cannot tell the read from the rows still arriving by LDS-DMA), which drains the row prefetch.  The asm
@@ -135,19 +140,34 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
     const void* src = ok ? (const void*)(xn + cb * xplane + ((long long)sy * p.x_w + sx) * 16 + half * 8) : p.zero;
     glds16wh(src, xring + (row % NXR) * XROWB + v * 1024);
   };
-  auto load_y = [&](int y, int v) {
-    const int q = v * 64 + lane;
+  // stage s = X tap-rows [y_begin + 2 + sR, +R) and dY rows [y_begin + sR, +R); exactly L loads per wave.  Which unit of which
+  // row a wave's uu-th load moves never changes, so its per-lane byte offset (channel block, column, half; beyond the buffer for
+  // lanes outside the image) is computed once; a step only adds the row as the scalar offset of the buffer load.
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)((long long)p.cin_blocks * xplane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dyn, 0, (unsigned)((long long)p.cout_blocks * yplane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0, 0x00020000);
+  unsigned lane_off[L];
+#pragma unroll
+  for (int uu = 0; uu < L; ++uu) {
+    const int u = uu * NW + wave;
+    const int v = u % (XUNITS + YUNITS);
+    const bool is_x = v < XUNITS;
+    const int q = (is_x ? v : v - XUNITS) * 64 + lane;
     const int plane = q / PLP, within = q - plane * PLP;
     const int px = within >> 1, half = within & 1;
-    const int cb = cout_tile0 * 2 + plane;
-    const int gx = x0 + px;
-    // rows at or below y_end belong to the next workgroup: they arrive as zeros, so the k-steps need no row guard
-    // (a guard around the MFMAs makes hipcc copy all 144 accumulator registers twice per step)
-    const bool ok = plane < CT * 2 && px < 64 && y < y_end && gx < p.W && cb < p.cout_blocks;
-    const void* src = ok ? (const void*)(dyn + cb * yplane + ((long long)y * p.W + gx) * 16 + half * 8) : p.zero;
-    glds16wh(src, yring + (y % NYR) * YROWB + v * 1024);
-  };
-  // stage s = X tap-rows [y_begin + 2 + sR, +R) and dY rows [y_begin + sR, +R); exactly L loads per wave
+    unsigned off = 0xfffffff0u;
+    if (is_x) {
+      const int cb = cin_tile0 * 2 + plane, gx = x0 - 1 + px;
+      if (plane < IT * 2 && px < 66 && gx >= 0 && gx < p.W && cb < p.cin_blocks)
+        off = (unsigned)((cb * xplane + (long long)(gx >> p.src_shift) * 16 + half * 8) * 2);
+    } else {
+      const int cb = cout_tile0 * 2 + plane, gx = x0 + px;
+      if (plane < CT * 2 && px < 64 && gx < p.W && cb < p.cout_blocks) off = (unsigned)((cb * yplane + (long long)gx * 16 + half * 8) * 2);
+    }
+    lane_off[uu] = off;
+  }
   auto issue = [&](int s) {
     const bool real = s < nsteps;
 #pragma unroll
@@ -155,12 +175,19 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
       const int u = uu * NW + wave;
       if (real && u < G::UNITS_PER_STAGE) {
         const int r = u / (XUNITS + YUNITS), v = u % (XUNITS + YUNITS);
-        if (v < XUNITS)
-          load_x(y_begin + 2 + s * R + r, v);
-        else
-          load_y(y_begin + s * R + r, v - XUNITS);
+        if (v < XUNITS) {
+          const int row = y_begin + 2 + s * R + r, vy = row - 1;
+          const bool ok = vy >= 0 && vy < p.H;
+          blds16(ok ? x_rs : null_rs, lane_off[uu], ok ? (unsigned)(vy >> p.src_shift) * (unsigned)p.x_w * 32u : 0u,
+                 xring + (row % NXR) * XROWB + v * 1024);
+        } else {
+          // rows at or below y_end belong to the next workgroup: they arrive as zeros, so the k-steps need no row guard
+          const int y = y_begin + s * R + r;
+          const bool ok = y < y_end;
+          blds16(ok ? y_rs : null_rs, lane_off[uu], ok ? (unsigned)y * (unsigned)p.W * 32u : 0u, yring + (y % NYR) * YROWB + (v - XUNITS) * 1024);
+        }
       } else {
-        glds16wh(p.zero, smem + DUMP);
+        blds16(null_rs, 0u, 0u, smem + DUMP);
       }
     }
   };
@@ -408,27 +435,46 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
     const void* src = ok ? (const void*)(xn + cb * plane_e + ((long long)vy * p.W + gx) * 16 + half * 8) : p.zero;
     glds16wh(src, xring + (row % NXR) * XROWB + v * 1024);
   };
-  auto load_y = [&](int y, int v) __attribute__((always_inline)) {
-    const int q = v * 64 + lane;
+  // stage s = X tap-row y_begin + 2 + s and dY row y_begin + s; exactly L loads per wave (load uu of the stage).  The unit a
+  // wave's uu-th load moves never changes: its per-lane byte offset is computed once, a step adds the row as the scalar offset
+  // of a buffer load (conv_f32.hip); a descriptor with num_records = 0 serves rows outside the image and the padding loads.
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)((long long)p.cin_blocks * plane_e * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dyn, 0, 0x7ffffff0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0, 0x00020000);
+  unsigned lane_off[L];
+#pragma unroll
+  for (int uu = 0; uu < L; ++uu) {
+    const int u = uu * 8 + wave;
+    const bool is_x = u < xunits;
+    const int q = (is_x ? u : u - xunits) * 64 + lane;
     const int plane = q / PLP, within = q - plane * PLP;
     const int px = within >> 1, half = within & 1;
-    const int a = plane >> 1, sub = plane & 1;
-    const int gx = x0 + px;
-    const int cbn = a ? im.dy_cbn_1 : im.dy_cbn_0, cb0 = a ? im.dy_cb0_1 : im.dy_cb0_0;
-    const bool ok = a < im.ndy && sub < cbn && px < 64 && y < y_end && gx < p.W;
-    const void* src = ok ? (const void*)(dyn + (cb0 + sub) * plane_e + ((long long)y * p.W + gx) * 16 + half * 8) : p.zero;
-    glds16wh(src, yring + (y % NYR) * YROWB + v * 1024);
-  };
-  // stage s = X tap-row y_begin + 2 + s and dY row y_begin + s; exactly L loads per wave (load uu of the stage)
+    unsigned off = 0xfffffff0u;
+    if (is_x) {
+      const int cb = im.x_tile0 * 2 + plane, gx = x0 - 1 + px;
+      if (plane < im.nx * 2 && px < 66 && gx >= 0 && gx < p.W && cb < p.cin_blocks) off = (unsigned)((cb * plane_e + (long long)gx * 16 + half * 8) * 2);
+    } else if (u < xunits + yunits) {
+      const int a = plane >> 1, sub = plane & 1, gx = x0 + px;
+      const int cbn = a ? im.dy_cbn_1 : im.dy_cbn_0, cb0 = a ? im.dy_cb0_1 : im.dy_cb0_0;
+      if (a < im.ndy && sub < cbn && px < 64 && gx < p.W) off = (unsigned)(((cb0 + sub) * plane_e + (long long)gx * 16 + half * 8) * 2);
+    }
+    lane_off[uu] = off;
+  }
   auto issue_one = [&](int s, int uu) __attribute__((always_inline)) {
     const bool real = s < nsteps;
     const int u = uu * 8 + wave;
-    if (real && u < xunits)
-      load_x(y_begin + 2 + s, u);
-    else if (real && u < xunits + yunits)
-      load_y(y_begin + s, u - xunits);
-    else
-      glds16wh(p.zero, smem + DUMP);
+    if (real && u < xunits) {
+      const int row = y_begin + 2 + s, vy = row - 1;
+      const bool ok = vy >= 0 && vy < p.H;
+      blds16(ok ? x_rs : null_rs, lane_off[uu], ok ? (unsigned)vy * (unsigned)p.W * 32u : 0u, xring + (row % NXR) * XROWB + u * 1024);
+    } else if (real && u < xunits + yunits) {
+      const int y = y_begin + s;
+      const bool ok = y < y_end;
+      blds16(ok ? y_rs : null_rs, lane_off[uu], ok ? (unsigned)y * (unsigned)p.W * 32u : 0u, yring + (y % NYR) * YROWB + (u - xunits) * 1024);
+    } else {
+      blds16(null_rs, 0u, 0u, smem + DUMP);
+    }
   };
   auto issue = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -884,6 +930,7 @@ extern "C" int sr_rdb_wgrad_bf16(const void* cat, const void* D, int64_t img_str
                                  void* stream) {
   SR_CHECK_ARG(cat && D && host_dparams && slab && n > 0 && h > 0 && w > 0 && nf > 0 && gc > 0, "sr_rdb_wgrad_bf16: bad argument");
   SR_CHECK_ARG(((uintptr_t)cat | (uintptr_t)D | (uintptr_t)slab) % 16 == 0, "sr_rdb_wgrad_bf16: pointers must be 16-byte aligned");
+  SR_CHECK_ARG((long long)h * w * 2 * (nf + 4 * gc + 15) < (1ll << 31), "sr_rdb_wgrad_bf16: image too large for 32-bit buffer offsets");
   return sr::rdb_wgrad_bf16(cat, D, img_stride, n, h, w, nf, gc, host_dparams, scale5, accumulate, slab, slab_bytes,
                             (hipStream_t)stream);
 }
@@ -892,6 +939,8 @@ extern "C" int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* strea
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(d && d->x && d->dy && d->dweight && d->slab, "sr_conv3x3_wgrad_bf16: null argument");
   SR_CHECK_ARG(d->cout > 0 && d->cin > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "sr_conv3x3_wgrad_bf16: bad shape");
+  SR_CHECK_ARG((long long)d->in_h * d->in_w * (d->upsample ? 4 : 1) * 2 * ((d->cout > d->cin_pad ? d->cout : d->cin_pad) + 15) < (1ll << 31),
+               "sr_conv3x3_wgrad_bf16: image too large for 32-bit buffer offsets");
   SR_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->slab) % 16 == 0,
                "sr_conv3x3_wgrad_bf16: pointers must be 16-byte aligned");
   const int cin_pad = sr_conv3x3_cin_pad16(d->cin, d->first_seg, d->seg);
