@@ -54,6 +54,12 @@ __device__ __forceinline__ void glds16w(const float* src, char* lds_dst) {
 
 // R = output rows per step.  R == KS: the KS waves of a pair split the step's rows;
 // R == 1 (with KS > 1): they split the 16 pixel-pair k-steps of the single row.
+// LDS-DMA through a buffer descriptor (kept in a __device__ function: called from the kernel body directly, the host pass of
+// hipcc drops the kernel's stub)
+__device__ __forceinline__ void blds16f(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
 template <int CT, int IT, int R, int KT>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,7 +103,39 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   char* yring = smem + XRING;
 
   // Stage the rows a step needs: X tap-rows u in [ux, ux+R) (virtual row u + tap_oy, ring slot u % NXR) and
-  // dY rows [yy, yy+R).  Units (1 KiB wave-instructions) are dealt round-robin to the 4 waves.
+  // dY rows [yy, yy+R).  Units (1 KiB wave-instructions) are dealt round-robin to the 4 waves.  Which unit of which row a wave's
+  // uu-th load moves never changes, so its per-lane byte offset (channel block, column, half; beyond the buffer for lanes outside
+  // the image) is computed once, and a step only adds the row as the scalar offset of a buffer-descriptor LDS-DMA
+  // (conv_f32.hip); a descriptor with num_records = 0 delivers the zero rows.
+  const __amdgpu_buffer_rsrc_t x_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)((long long)p.cin_blocks * xplane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dyn, 0, (unsigned)((long long)p.cout_blocks * yplane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0, 0x00020000);
+  unsigned lane_off[UPW];
+#pragma unroll
+  for (int uu = 0; uu < UPW; ++uu) {
+    const int u = uu * 4 + wave;
+    const int v = u % (XUNITS + YUNITS);
+    unsigned off = 0xfffffff0u;
+    if (v < XUNITS) {
+      const int q = v * 64 + lane;
+      const int pix = q / (XCH / 4), c4 = q % (XCH / 4);
+      const int cb = cin_tile0 * 4 + (c4 >> 1);
+      const int gx = x0 + p.tap_ox + pix;
+      if (q < XPIECES && gx >= 0 && gx < p.vW && cb < p.cin_blocks) {
+        const int sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
+        off = (unsigned)((cb * xplane + (long long)sx * 8 + (c4 & 1) * 4) * 4);
+      }
+    } else {
+      const int q = (v - XUNITS) * 64 + lane;
+      const int pix = q / (YCH / 4), c4 = q % (YCH / 4);
+      const int cb = cout_tile0 * 4 + (c4 >> 1);
+      const int gx = x0 + pix;
+      if (gx < p.W && cb < p.cout_blocks) off = (unsigned)((cb * yplane + (long long)gx * 8 + (c4 & 1) * 4) * 4);
+    }
+    lane_off[uu] = off;
+  }
   auto stage = [&](int ux, int yy, bool with_dy) {
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
@@ -106,28 +144,15 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
       const int r = u / (XUNITS + YUNITS), v = u % (XUNITS + YUNITS);
       if (v >= XUNITS && !with_dy) continue;
       if (v < XUNITS) {
-        const int u = ux + r;
-        const int vy = u + p.tap_oy;  // virtual source row; outside [0, vH) = zero row
-        const int q = v * 64 + lane;
-        const int pix = q / (XCH / 4), c4 = q % (XCH / 4);
-        const int cb = cin_tile0 * 4 + (c4 >> 1);
-        const int gx = x0 + p.tap_ox + pix;
-        const bool ok = (q < XPIECES) && vy >= 0 && vy < p.vH && gx >= 0 && gx < p.vW && cb < p.cin_blocks;
-        const int sy = ((vy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
-        const float* src = ok ? xn + cb * xplane + ((long long)sy * p.x_w + sx) * 8 + (c4 & 1) * 4 : (const float*)p.zero;
-        const int slot = u % NXR;
-        glds16w(src, xring + slot * XROWB + v * 1024);
+        const int ur = ux + r;
+        const int vy = ur + p.tap_oy;  // virtual source row; outside [0, vH) = zero row
+        const bool ok = vy >= 0 && vy < p.vH;
+        const int sy = ((vy * p.src_mul) >> p.src_shift) + p.src_oy;
+        blds16f(ok ? x_rs : null_rs, lane_off[uu], ok ? (unsigned)sy * (unsigned)p.x_w * 32u : 0u, xring + (ur % NXR) * XROWB + v * 1024);
       } else {
-        const int vy = v - XUNITS;
         const int y = yy + r;
-        const int q = vy * 64 + lane;
-        const int pix = q / (YCH / 4), c4 = q % (YCH / 4);
-        const int cb = cout_tile0 * 4 + (c4 >> 1);
-        const int gx = x0 + pix;
-        const bool ok = y < p.H && gx < p.W && cb < p.cout_blocks;
-        const float* src = ok ? dyn + cb * yplane + ((long long)y * p.W + gx) * 8 + (c4 & 1) * 4 : (const float*)p.zero;
-        const int slot = y % NYR;
-        glds16w(src, yring + slot * YROWB + vy * 1024);
+        const bool ok = y < p.H;
+        blds16f(ok ? y_rs : null_rs, lane_off[uu], ok ? (unsigned)y * (unsigned)p.W * 32u : 0u, yring + (y % NYR) * YROWB + (v - XUNITS) * 1024);
       }
     }
   };
@@ -693,6 +718,8 @@ int run_groups(const sr_conv3x3_wgrad_desc* d, const WgradParams& p, int cin_pad
 int fill_wgrad(const sr_conv3x3_wgrad_desc* d, WgradParams* pp, const char* who) {
   SR_CHECK_ARG(d && d->x && d->dy && d->dweight && d->slab, "%s: null argument", who);
   SR_CHECK_ARG(d->cout > 0 && d->cin > 0 && d->n > 0 && d->in_h > 0 && d->in_w > 0, "%s: bad shape", who);
+  SR_CHECK_ARG((long long)d->in_h * d->in_w * 4 * 4 * ((d->cout > d->cin_pad ? d->cout : d->cin_pad) + 7) < (1ll << 32),
+               "%s: image too large for 32-bit buffer offsets", who);
   SR_CHECK_ARG(((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->slab) % 16 == 0, "%s: pointers must be 16-byte aligned",
                who);
   WgradParams& p = *pp;
