@@ -701,6 +701,11 @@ int launch_small(ConvParams q, const sr_conv3x3_desc* d, int groups, int gc, hip
 // wave-slot time of the one-round conv1-4 launches, but runs conv5 as two 32-cout items and pays the hand-offs.
 static bool g_chain_f32_enabled = false;
 static bool g_f32_tall64 = false;
+static int g_f32_rows8 = 1;  // 32-cout convs on 8-row tiles (1, default: two rounds of workgroups) / 4-row tiles (2) / 16-row tiles (0)
+extern "C" int sr_dev_set_f32_rows8(int on) {  // development switch: 32-cout convs on 8-row tiles (two rounds of workgroups)
+  g_f32_rows8 = on;
+  return SR_OK;
+}
 extern "C" int sr_dev_set_f32_tall64(int on) {  // development switch (not in the ABI header)
   g_f32_tall64 = on != 0;
   return SR_OK;
@@ -850,9 +855,13 @@ extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
   // 32-cout groups: 16-row tiles (PT = 4) halve the weight refill per MFMA (measured +2.5..7 % on the RDB conv1-4
   // shapes, tools/conv_ablate.hip) as long as the launch still has >= 2 workgroups per CU and rows are not wasted.
   const long long wg4 = (long long)p.tiles_x * sr::cdiv(p.H, 16) * d->n * groups;
-  if (p.H % 16 == 0 && wg4 >= 512) {
+  if (p.H % 16 == 0 && wg4 >= 512 && !g_f32_rows8) {
     p.tiles_y = sr::cdiv(p.H, 16);
     return launch<1, 4, 3, false>(p, d->n, groups, stream, d);
+  }
+  if (g_f32_rows8 == 2) {
+    p.tiles_y = sr::cdiv(p.H, 4);
+    return launch<1, 1, 3, false>(p, d->n, groups, stream, d);
   }
   return launch<1, PT, 3, false>(p, d->n, groups, stream, d);
 }
