@@ -69,7 +69,7 @@ __device__ __forceinline__ void store16(void* ptr, u32x4_t v, bool write_through
   if (write_through)
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory");
   else
-    *(u32x4_t*)ptr = v;
+    *(__attribute__((address_space(1))) u32x4_t*)ptr = v;  // global, also where the pointer's origin is opaque (conv_params)
 }
 
 // CB16 epilogue of a tile: bias, LeakyReLU, scale, residual scale-adds, LeakyReLU-backward mask in fp32, then bf16 stores.
@@ -81,9 +81,10 @@ __device__ __forceinline__ void store16(void* ptr, u32x4_t v, bool write_through
 // ones in the chain kernel: 6-16 thousand cycles per tile.  Pass 1 loads the bias values once, then finishes every value in place
 // in the accumulators (its residual / mask loads only queue behind other loads); pass 2 converts and stores.  Per element the
 // operations and their order are unchanged (results are bit-identical).
-template <int COT, int PT, bool WT_OUT>
+template <int COT, int PT, bool WT_OUT, bool BIAS_LDS = false>
 __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc)[COT][PT], const int cog, const int n, const int x,
-                                              const int y_first, const int h) {
+                                              const int y_first, const int h,
+                                              const __attribute__((address_space(3))) float* lbias = nullptr) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   auto swap_halves = [](u32x4& t) {  // t[0..1].upper-lanes <-> t[2..3].lower-lanes
     auto r0 = __builtin_amdgcn_permlane32_swap(t[0], t[2], false, false);
@@ -102,7 +103,10 @@ __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc
   for (int c = 0; c < COT; ++c)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      bias[c][g] = p.bias ? *(const f32x4*)(p.bias + (cog * COT + c) * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (BIAS_LDS)  // the caller keeps the packed bias in the LDS (no vector-memory load behind its LDS-DMA queue)
+        bias[c][g] = *(const __attribute__((address_space(3))) f32x4*)(lbias + (cog * COT + c) * 32 + g * 8 + h * 4);
+      else
+        bias[c][g] = p.bias ? *(const f32x4*)(p.bias + (cog * COT + c) * 32 + g * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   // pass 1
 #pragma unroll
   for (int r = 0; r < PT; ++r) {
@@ -128,7 +132,7 @@ __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc
           v[q] *= p.alpha;
         }
         auto add_res = [&](const char* res, long long nb, float beta) {
-          u32x4 rr = *(const u32x4*)(res + (long long)n * nb + off);  // channels 8h..8h+7
+          u32x4 rr = *(const __attribute__((address_space(1))) u32x4*)(res + (long long)n * nb + off);  // channels 8h..8h+7
           swap_halves(rr);  // -> rr[0..1] = quad 2m, rr[2..3] = quad 2m+1 of this lane
 #pragma unroll
           for (int q = 0; q < 2; ++q)
@@ -138,7 +142,7 @@ __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc
         if (p.res1) add_res(p.res1, p.res1_nb, p.beta1);
         if (p.res2) add_res(p.res2, p.res2_nb, p.beta2);
         if (p.mask && cb < p.mask_cbn) {
-          u32x4 mm = *(const u32x4*)(p.mask + (long long)n * p.mask_nb + off);
+          u32x4 mm = *(const __attribute__((address_space(1))) u32x4*)(p.mask + (long long)n * p.mask_nb + off);
           swap_halves(mm);
 #pragma unroll
           for (int q = 0; q < 2; ++q)
@@ -765,6 +769,482 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused dense block
+// The dense block re-associated so that every input is staged ONCE.  conv k reads the concat [x | x1 .. x(k-1)]: launched conv by
+// conv (or item by item in the chain kernel above) x crosses L2 -> LDS five times, x1 four times ... — 640 channel-reads for 192
+// distinct channels, and at bf16 rates that fill traffic, not the MFMA, sets the pace (conv1-4: 288 FLOP per staged byte).  Here a
+// workgroup owns one 16x32-pixel tile for the whole block and keeps the partial sums of ALL unfinished convs in registers:
+//   input group I_s (x for s = 0, else x_s):  acc_k += W_k[:, I_s] * I_s   for every conv k > s
+// Once conv s+1 has seen I_s it is complete: bias / LeakyReLU / write-through store / publish, and x_(s+1) becomes an input.
+// Per accumulator the MFMA sequence (chunk order, then tap column, then tap row) is the one of conv_tile_h, so results are
+// bit-identical to the conv-by-conv path.  Registers: 6 accumulator groups (conv1-4: 32 couts, conv5: 2 x 32) x 2 tile rows x 16
+// fp32 per lane, at most 160 live; 8 waves per workgroup, one workgroup per CU.
+// LDS (154 KB): six 20 KB tile buffers (x: 0-3, x1: 4-5, x2: 0-1, x3: 2-3, x4: 4-5 — the next input's tile lands while the current
+// ones are multiplied) + a 32-piece ring of 1 KB weight pieces that streams the 468 pieces of the block in consumption order + the
+// biases + a landing pad for the neighbour flags.
+// Every step (a chunk x tap-column range x accumulator groups) begins with a COUNTED s_waitcnt vmcnt + raw s_barrier; what may stay
+// in flight at each wait is computed at compile time from the static issue sequence (make_sched; vector-memory operations retire in
+// issue order), and every wave issues the same number of LDS-DMA instructions per step (pieces are dealt out in groups of eight).
+// Hand-off between tiles, with nothing drained: a conv's tile leaves with write-through stores and is published a few steps later,
+// at a step whose counted wait covers those stores; wave 0 fetches its nine neighbours' progress words by LDS-DMA (agent scope) a
+// few steps before the dependent tile is issued and inspects them behind a counted wait; the dependent tile itself is loaded at agent
+// scope (sc1: no cache invalidate).  The phases are ordered so that every hand-off (store -> publish -> flag -> halo fetch, ~4
+// memory round trips) runs under MFMAs that do not depend on it: after conv k's own phase come partial sums of later convs over
+// inputs that are already in the LDS (conv5's are deferred as far as its accumulation order allows).
+// A tile's workgroup waits for its 8 neighbours at every hand-off, so all tiles of an image must be resident together: the grid is
+// (images per round) x (tiles per image) <= CUs, and the host falls back to the chain kernel when an image has more tiles than CUs.
+namespace fz {
+constexpr int NW = 8, PT = 2, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+constexpr int XU = 20, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer (18 x 34 pixels x 32 B, rounded up)
+constexpr int RING = 32;                            // weight ring, pieces
+constexpr int LDS_W0 = NTB * XBUF;
+constexpr int LDS_FLAGS = LDS_W0 + RING * 1024;     // 64 words: neighbour progress words land here
+constexpr int LDS_BIAS = LDS_FLAGS + 256;           // 5 x 64 floats
+constexpr int LDS_BYTES = LDS_BIAS + 5 * 64 * 4;
+constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
+constexpr int MAXSTEPS = 80, MAXP = 512;
+constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
+
+struct StepD {
+  int in, chunk, g0, ng, dx0, ndx, tb;
+  int wp0, wpn;     // weight pieces [wp0, wp0 + wpn) of the stream, order (tap column, group, tap row)
+  int post;         // k in 1..5: conv k is complete after this step (epilogue)
+  int K;            // vector-memory instructions of this wave that may still be in flight when the step starts
+  int q0, q1;       // weight piece groups [q0, q1) issued after the step's barrier
+  int publish;      // k in 1..4: conv k's tile is published after the step's barrier (its stores are covered by K)
+  int tile_in;      // > 0: the tile of input group tile_in is issued after the step's barrier (neighbour flags inspected before it)
+  int flag_in;      // > 0: wave 0 fetches the neighbour flags for input group flag_in during this step
+  int Kflag;        // tile_in > 0: instructions younger than that flag fetch
+  int zero_mask;    // accumulator groups that start with this step
+  int first_of_in;  // > 0: first step that reads input group first_of_in
+};
+struct Sched {
+  int nsteps, npieces, ngroups, q_init, ok;
+  StepD st[MAXSTEPS];
+  unsigned wtab[MAXP];  // per piece: conv (4 bits) << 28 | byte offset inside that conv's packed image
+};
+
+// phases in execution order: {input group, first chunk, end chunk, first accumulator group, groups, one step per tap column (else per
+// chunk), conv completed}.  After conv k's own phase come partial sums that do not depend on x_k, ~144 MFMAs per wave and hand-off.
+constexpr int kNPhase = 13;
+constexpr int kPhase[kNPhase][7] = {{0, 0, 4, 0, 1, 0, 1},                                              // conv1 x
+                                    {0, 0, 4, 1, 2, 1, 0}, {0, 0, 2, 3, 3, 1, 0},                       //   conv2-3 x | conv4-5 x[0,1]
+                                    {1, 0, 2, 1, 1, 0, 2},                                              // conv2 x1
+                                    {0, 2, 4, 3, 3, 1, 0}, {1, 0, 2, 2, 1, 0, 0},                       //   conv4-5 x[2,3] | conv3 x1
+                                    {2, 0, 2, 2, 1, 0, 3},                                              // conv3 x2
+                                    {1, 0, 2, 3, 3, 1, 0}, {2, 0, 2, 3, 1, 0, 0},                       //   conv4-5 x1 | conv4 x2
+                                    {3, 0, 2, 3, 1, 0, 4},                                              // conv4 x3
+                                    {2, 0, 2, 4, 2, 1, 0}, {3, 0, 2, 4, 2, 1, 0},                       //   conv5 x2 | conv5 x3
+                                    {4, 0, 2, 4, 2, 1, 5}};                                             // conv5 x4
+constexpr int kPubLag[4] = {4, 2, 2, 3};    // steps from conv k's epilogue to its publish
+constexpr int kTileLag[4] = {5, 4, 4, 5};   // steps from the publish to the fetch of the dependent tile
+constexpr int kFlagLead[4] = {4, 3, 3, 4};  // the flags are fetched this many steps before they are inspected
+constexpr int in_chunks(int s) { return s == 0 ? 4 : 2; }
+constexpr int in_cb0(int s) { return s == 0 ? 0 : 4 + 2 * (s - 1); }
+constexpr int in_tb0(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 0 : s == 3 ? 2 : 4; }
+
+constexpr Sched make_sched() {
+  Sched s{};
+  int ns = 0, np = 0, seen = 0;
+  int post_step[6] = {-1, -1, -1, -1, -1, -1}, first_use[5] = {-1, -1, -1, -1, -1};
+  for (int ph = 0; ph < kNPhase; ++ph) {
+    const int in = kPhase[ph][0], g0 = kPhase[ph][3], ng = kPhase[ph][4], perdx = kPhase[ph][5];
+    for (int c = kPhase[ph][1]; c < kPhase[ph][2]; ++c)
+      for (int part = 0; part < (perdx ? 3 : 1); ++part) {
+        StepD& d = s.st[ns];
+        d.in = in;
+        d.chunk = c;
+        d.g0 = g0;
+        d.ng = ng;
+        d.dx0 = perdx ? part : 0;
+        d.ndx = perdx ? 1 : 3;
+        d.tb = in_tb0(in) + c;
+        d.wp0 = np;
+        d.wpn = d.ndx * ng * 3;
+        for (int j = 0; j < d.wpn; ++j) {
+          const int dx = d.dx0 + j / (ng * 3), g = g0 + (j / 3) % ng, dy = j % 3;
+          const int k = g < 4 ? g : 4, cot = g < 4 ? 1 : 2, cc = g < 4 ? 0 : g - 4;
+          const int cb = in_cb0(in) + c;
+          s.wtab[np + j] = ((unsigned)k << 28) | (unsigned)((cb * 9 * cot + (dy * 3 + dx) * cot + cc) * 1024);
+        }
+        np += d.wpn;
+        for (int g = g0; g < g0 + ng; ++g)
+          if (!(seen >> g & 1)) {
+            d.zero_mask |= 1 << g;
+            seen |= 1 << g;
+          }
+        if (first_use[in] < 0) {
+          first_use[in] = ns;
+          d.first_of_in = in;
+        }
+        ++ns;
+      }
+    if (kPhase[ph][6]) {
+      s.st[ns - 1].post = kPhase[ph][6];
+      post_step[kPhase[ph][6]] = ns - 1;
+    }
+  }
+  s.nsteps = ns;
+  s.npieces = np;
+  while (np % 8) {  // whole groups of eight: the padding re-loads piece 0 into a free slot
+    s.wtab[np] = s.wtab[0];
+    ++np;
+  }
+  s.ngroups = np / 8;
+  s.ok = 1;
+  int issue_step[5] = {-1, 0, 0, 0, 0}, last_use[5] = {0, 0, 0, 0, 0};
+  for (int j = 0; j < ns; ++j) last_use[s.st[j].in] = j;
+  for (int t = 1; t <= 4; ++t) {  // conv t -> input group t
+    const int pub = post_step[t] + kPubLag[t - 1], ti = pub + kTileLag[t - 1], tf = ti - kFlagLead[t - 1];
+    if (post_step[t] < 0 || tf <= pub || ti >= first_use[t]) s.ok = 0;
+    s.st[pub].publish = t;
+    s.st[ti].tile_in = t;
+    s.st[tf].flag_in = t;
+    issue_step[t] = ti;
+  }
+  // a tile buffer is never refilled while its previous content is still read: last read of the old input < issue step of the new one
+  for (int t = 1; t <= 4; ++t)
+    for (int j = 0; j < ns; ++j) {
+      const bool same_buf = s.st[j].tb == in_tb0(t) || s.st[j].tb == in_tb0(t) + 1;
+      if (same_buf && s.st[j].in != t && j >= issue_step[t] && j <= last_use[t]) s.ok = 0;  // somebody else reads it while t owns it
+      if (same_buf && s.st[j].in == t && j < issue_step[t]) s.ok = 0;
+    }
+  // the issue sequence of one wave: what is younger than the operations a step needs may stay in flight at its wait
+  int seq = 0, gend[MAXP / 8] = {}, tend[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, send[5] = {0, 0, 0, 0, 0}, fseq[5] = {0, 0, 0, 0, 0};
+  seq += 5;  // chunks 0-1 of x: 40 pieces = 5 per wave
+  tend[0][0] = seq;
+  seq += 5;  // chunks 2-3
+  tend[0][1] = seq;
+  int issued = RING / 8;
+  s.q_init = issued;
+  for (int q = 0; q < issued; ++q) gend[q] = ++seq;
+  for (int i = 0; i < ns; ++i) {
+    StepD& d = s.st[i];
+    const int qn = (d.wp0 + d.wpn - 1) / 8;
+    const int te = tend[d.in][d.chunk / 2];
+    if (gend[qn] == 0 || te == 0 || d.wpn > RING) s.ok = 0;
+    int need = gend[qn] > te ? gend[qn] : te;
+    if (d.publish) {
+      if (send[d.publish] == 0) s.ok = 0;
+      if (send[d.publish] > need) need = send[d.publish];
+    }
+    d.K = seq - need;
+    if (d.tile_in) {
+      d.Kflag = seq - fseq[d.tile_in];
+      seq += 5;  // two chunks: 40 pieces
+      tend[d.tile_in][0] = seq;
+    }
+    int q1 = (d.wp0 + RING) / 8;
+    if (q1 > s.ngroups) q1 = s.ngroups;
+    d.q0 = issued;
+    d.q1 = q1;
+    for (int q = issued; q < q1; ++q) gend[q] = ++seq;
+    issued = q1;
+    if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
+    if (d.post >= 1 && d.post <= 4) {
+      seq += 4;  // the epilogue's stores: 2 rows x 2 channel blocks
+      send[d.post] = seq;
+    }
+    if (d.K > 60 || d.Kflag > 60) s.ok = 0;
+  }
+  if (issued != s.ngroups) s.ok = 0;
+  return s;
+}
+constexpr Sched kS = make_sched();
+static_assert(kS.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
+struct WTab {
+  unsigned v[MAXP];
+};
+constexpr WTab make_wtab() {
+  WTab t{};
+  for (int i = 0; i < MAXP; ++i) t.v[i] = i < kS.ngroups * 8 ? kS.wtab[i] : kS.wtab[0];
+  return t;
+}
+__device__ const WTab kWTabDev = make_wtab();
+
+struct FusedParams {
+  ConvParamsH lv[5];   // first member: conv_params() reads it from the kernel argument segment
+  unsigned wdelta[5];  // byte offset of conv k's packed image from wbase
+  const char* wbase;
+  unsigned wspan;      // bytes covered by the five images from wbase
+  int n, ipr, tiles_x, tiles_y;  // images, images per round, tile grid of an image
+  int* done;
+  int* abort;
+  int epoch;
+  long long* dbg;
+};
+
+template <int K>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+
+typedef __attribute__((address_space(3))) int* lds_int_p;
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+struct Env {
+  char* smem;
+  lds_int_p ctl;       // LDS word: a dependency wait timed out
+  int lane, wave, tid;
+  int n, tile, x, y_first, h;  // image, tile of the batch, this lane's output column, this wave's first row, lane half
+  unsigned xvo[5];     // lane offsets of this wave's five tile pieces (per pair of chunks)
+  unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
+  unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
+  unsigned T[8];       // lane l of T[m]: source offset of weight piece 64 m + l
+  unsigned plane_b;
+  int xl[3];           // LDS byte offset of this lane's pixel operand at tap column dx (tile row of the wave)
+  int wlane;           // LDS byte offset of this lane's weight operand inside a piece
+  const int* flag_ptr; // lanes 0-8 of wave 0: progress word of a neighbour tile (null: outside the image)
+  long long* dbg;
+};
+
+template <int AUX>
+__device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0) {
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int u = r * NW + e.wave;
+    const int ci = u >= XU ? 1 : 0, pc = u - ci * XU;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + (tb0 + ci) * XBUF + pc * 1024), 16, e.xvo[r],
+                                             (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void issue_wgroup(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
+  const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)e.T[Q / 8], (Q % 8) * 8 + e.wave);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_p)(e.smem + LDS_W0 + (((Q * 8) % RING) + e.wave) * 1024), 16, e.wvo, so, 0, 0);
+}
+template <int Q, int Q1>
+__device__ __forceinline__ void issue_wgroups(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
+  if constexpr (Q < Q1) {
+    issue_wgroup<Q>(e, w_rs);
+    issue_wgroups<Q + 1, Q1>(e, w_rs);
+  }
+}
+
+// the MFMAs of step S: units (tap column, group) in order, the operands of the next unit read before this unit's MFMAs
+template <int S>
+__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT]) {
+  constexpr StepD d = kS.st[S];
+  constexpr int NU = d.ndx * d.ng;
+  bf16x8 bx[2][PT + 2], a[2][3];
+  const char* xb = e.smem + d.tb * XBUF;
+  const char* wb = e.smem + LDS_W0 + e.wlane;
+  auto ld_bx = [&](int slot, int dx) {
+#pragma unroll
+    for (int r = 0; r < PT + 2; ++r) bx[slot][r] = *(const bf16x8*)(xb + e.xl[dx] + r * XROW * 32);
+  };
+  auto ld_a = [&](int slot, int u) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) a[slot][dy] = *(const bf16x8*)(wb + ((d.wp0 + u * 3 + dy) % RING) * 1024);
+  };
+  ld_bx(0, d.dx0);
+  ld_a(0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int dxi = u / d.ng, g = d.g0 + u % d.ng;
+    if (u + 1 < NU) {
+      if ((u + 1) % d.ng == 0) ld_bx((dxi + 1) & 1, d.dx0 + dxi + 1);
+      ld_a((u + 1) & 1, u + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int r = 0; r < PT; ++r)
+        acc[g][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 1][dy], bx[dxi & 1][r + dy], acc[g][r], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// conv k's parameters, read from the kernel argument segment where they are used: as plain kernel arguments the ~140 scalars of the
+// five epilogues are loaded at the top of the kernel and spilled (the offset passes through an empty asm so that the loads cannot be
+// hoisted)
+__device__ __forceinline__ ConvParamsH conv_params(int k) {
+  unsigned off = (unsigned)(k * sizeof(ConvParamsH));  // FusedParams::lv is the first member
+  asm volatile("" : "+s"(off));
+  typedef const __attribute__((address_space(4))) unsigned* kernarg_words;
+  kernarg_words src = (kernarg_words)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  static_assert(sizeof(ConvParamsH) % 4 == 0, "ConvParamsH is copied word by word");
+  unsigned words[sizeof(ConvParamsH) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(ConvParamsH) / 4; ++i) words[i] = src[i];
+  ConvParamsH r;
+  __builtin_memcpy(&r, words, sizeof(r));
+  return r;
+}
+
+__device__ __forceinline__ void stamp(const Env& e, int i) {
+  if (e.dbg && e.tid == 0) e.dbg[i] = __builtin_readcyclecounter();
+}
+
+template <int S>
+__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+                                        const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
+  constexpr StepD d = kS.st[S];
+  if constexpr (d.publish > 0) stamp(e, 2 + 8 * (d.publish - 1) + 2);
+  if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 6);
+  if constexpr (d.tile_in > 0) {  // the neighbours' conv `tile_in` must be published before its tile is fetched
+    stamp(e, 2 + 8 * (d.tile_in - 1) + 4);
+    if (e.wave == 0) {
+      wait_vm<d.Kflag>();  // the flag fetch of a few steps ago has landed
+      bool gave_up = false;
+      if (e.flag_ptr) {
+        const int want = P.epoch + d.tile_in;
+        int v = *(volatile lds_int_p)(e.smem + LDS_FLAGS + e.lane * 4), spins = 0;
+        while (v < want) {
+          __builtin_amdgcn_s_sleep(2);
+          v = flag_load(e.flag_ptr);
+          if ((++spins & 255) == 0 && (spins > (1 << 22) || flag_load(P.abort))) {
+            __hip_atomic_store(P.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+            break;
+          }
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(gave_up)) {
+        if (e.lane == 0) *(volatile lds_int_p)e.ctl = 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  }
+  wait_vm<d.K>();
+  __builtin_amdgcn_s_barrier();
+  if constexpr (S == 0) stamp(e, 1);
+  if constexpr (d.tile_in > 0) stamp(e, 2 + 8 * (d.tile_in - 1) + 5);
+  if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 7);
+  if constexpr (d.publish > 0) {  // every wave's stores of conv `publish` have landed (K covers them)
+    if (e.tid == 0) __hip_atomic_store(P.done + e.tile, P.epoch + d.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(e, 2 + 8 * (d.publish - 1) + 3);
+  }
+  if constexpr (d.tile_in > 0) {
+    if (*(volatile lds_int_p)e.ctl) return false;
+    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in));  // agent scope: written by other workgroups of this launch
+  }
+  issue_wgroups<d.q0, d.q1>(e, w_rs);
+  if constexpr (d.flag_in > 0) {
+    if (e.wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
+  }
+  if constexpr (d.post > 0 && d.post < 5) stamp(e, 2 + 8 * (d.post - 1));  // last step of conv `post` runs
+  if constexpr (d.post == 5) stamp(e, 40);
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    if (d.zero_mask >> g & 1) {
+#pragma unroll
+      for (int r = 0; r < PT; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][r][i] = 0.f;
+    }
+  compute_step<S>(e, acc);
+  typedef const __attribute__((address_space(3))) float* lds_float_p;
+  if constexpr (d.post > 0 && d.post < 5) {
+    const ConvParamsH lp = conv_params(d.post - 1);
+    epilogue_cb16<1, PT, true, true>(lp, reinterpret_cast<f32x16(&)[1][PT]>(acc[d.post - 1]), 0, e.n, e.x, e.y_first, e.h,
+                                     (lds_float_p)(e.smem + LDS_BIAS + (d.post - 1) * 256));
+    stamp(e, 2 + 8 * (d.post - 1) + 1);
+  } else if constexpr (d.post == 5) {
+    stamp(e, 41);
+    const ConvParamsH lp = conv_params(4);
+    epilogue_cb16<2, PT, false, true>(lp, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), 0, e.n, e.x, e.y_first, e.h,
+                                      (lds_float_p)(e.smem + LDS_BIAS + 4 * 256));
+  }
+  return true;
+}
+
+template <int S>
+__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+                                          const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
+  if constexpr (S < kS.nsteps) {
+    if (!do_step<S>(e, acc, P, x_rs, w_rs, f_rs)) return false;
+    return run_steps<S + 1>(e, acc, P, x_rs, w_rs, f_rs);
+  } else {
+    return true;
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+}  // namespace fz
+
+__global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedParams P) {
+  using namespace fz;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_ctl;
+  Env e;
+  e.smem = smem;
+  e.ctl = (lds_int_p)&s_ctl;
+  e.tid = threadIdx.x;
+  e.lane = e.tid & 63;
+  e.wave = __builtin_amdgcn_readfirstlane(e.tid >> 6);
+  e.dbg = P.dbg ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
+  const int j = e.lane & 31;
+  e.h = e.lane >> 5;
+  const ConvParamsH& p0 = P.lv[0];
+  e.plane_b = (unsigned)(p0.H * p0.W * 32);
+  e.wvo = (e.lane ^ ((e.lane >> 4) & 1)) * 16;
+  e.wlane = j * 32 + ((e.h ^ ((j >> 3) & 1)) * 16);
+  const int xrow0 = ((e.wave * PT) * XROW + j) * 32;
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) e.xl[dx] = xrow0 + dx * 32 + ((e.h ^ (((j + dx) >> 3) & 1)) * 16);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const unsigned t = kWTabDev.v[m * 64 + e.lane];
+    const unsigned k = t >> 28;
+    const unsigned dlt = k == 0 ? P.wdelta[0] : k == 1 ? P.wdelta[1] : k == 2 ? P.wdelta[2] : k == 3 ? P.wdelta[3] : P.wdelta[4];
+    e.T[m] = dlt + (t & 0x0fffffffu);
+  }
+  const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(P.wbase, P.wspan);
+  if (e.tid == 0) s_ctl = 0;
+  if (e.tid < 5 * 64) {  // the five packed biases (conv1-4: 32 floats, conv5: 64; zeros when a conv has none)
+    const int k = e.tid >> 6, i = e.tid & 63;
+    const float* b = P.lv[k].bias;
+    ((float*)(smem + LDS_BIAS))[e.tid] = (b && i < (k < 4 ? 32 : 64)) ? b[i] : 0.f;
+  }
+  const int T = P.tiles_x * P.tiles_y;
+  const int slot = blockIdx.x / T;
+  int t = blockIdx.x - slot * T;
+  const int tx = t % P.tiles_x, ty = t / P.tiles_x;
+  const int x0 = tx * 32, y0 = ty * TH;
+  e.x = x0 + j;
+  e.y_first = y0 + e.wave * PT;
+  // lane offsets of this wave's tile pieces (they do not depend on the image)
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int u = r * NW + e.wave;
+    const int pc = u >= XU ? u - XU : u;
+    const int q = pc * 64 + e.lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool valid = pix < XPIX && gy >= 0 && gy < p0.H && gx >= 0 && gx < p0.W;
+    e.xvo[r] = valid ? (unsigned)((gy * p0.W + gx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : 0xfffffff0u;
+  }
+  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
+  int nb = -1;
+  if (e.wave == 0 && e.lane < 9) {
+    const int ny = ty + e.lane / 3 - 1, nx = tx + e.lane % 3 - 1;
+    if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) nb = ny * P.tiles_x + nx;
+  }
+  e.fvo = nb >= 0 ? (unsigned)nb * 4u : 0xfffffff0u;
+  for (int round = 0;; ++round) {
+    e.n = round * P.ipr + slot;
+    if (e.n >= P.n) break;
+    e.tile = e.n * T + ty * P.tiles_x + tx;
+    e.flag_ptr = nb >= 0 ? P.done + e.n * T + nb : nullptr;
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(p0.in + (long long)e.n * p0.in_nb, 12u * e.plane_b);
+    const __amdgpu_buffer_rsrc_t f_rs = make_rsrc(P.done + e.n * T, (unsigned)T * 4u);
+    __syncthreads();  // the previous round's LDS reads are over (first round: s_ctl and the biases are set)
+    stamp(e, 0);
+    issue_tile_pair<0>(e, x_rs, 0, 0);
+    issue_tile_pair<0>(e, x_rs, 2, 2);
+    issue_wgroups<0, kS.q_init>(e, w_rs);
+    f32x16 acc[NG][PT];
+    if (!run_steps<0>(e, acc, P, x_rs, w_rs, f_rs)) break;
+    stamp(e, 42);
+  }
+}
+
 template <int COT, int PT, int NW>
 constexpr int conv_bf16_lds() {
   return 2 * ((((NW * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
@@ -867,7 +1347,8 @@ extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
 // 1502 img/s, mode 2 1541, mode 1 (32-row ring tiles, one workgroup per CU) 1458; a dense block alone 159 -> 147 us at batch 16,
 // 310 -> 272 us at batch 32, 771 -> 664 us on four 544x544 tiler cells.  With two workgroups per CU one's hand-off, prologue and
 // epilogue overlap the other's MFMA loop; the single 32-row workgroup has nothing to overlap them with.
-static int g_chain_enabled = 2;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU)
+static int g_chain_enabled = 2;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
+                                 // 3 = fused dense block (rdb_fused_bf16_kernel) where eligible, else as 2
 static long long* g_chain_clocks = nullptr;
 // Development aid (tools/chain_phase.py; not part of the ABI): per work item, wave 0 writes claim / wait / acquire / tile / drain clocks.
 extern "C" void sr_dev_chain_phase_clocks(void* buf) { g_chain_clocks = (long long*)buf; }
@@ -876,12 +1357,91 @@ extern "C" int sr_set_conv_chain(int enabled) {
   return SR_OK;
 }
 
+static long long* g_fused_clocks = nullptr;
+// Development aid (tools/fused_phase.py; not part of the ABI): 32 cycle stamps per workgroup of the fused dense-block kernel.
+extern "C" void sr_dev_fused_phase_clocks(void* buf) { g_fused_clocks = (long long*)buf; }
+
+// The dense block as rdb_fused_bf16_kernel when the five descriptors are one (64 + 4 x 32 channel) block over a single concat buffer and
+// every image's tiles fit the chip together; *launched says whether it ran.
+static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int call_index, hipStream_t stream, bool* launched) {
+  *launched = false;
+  const int n = d[0].n, h = d[0].in_h, w = d[0].in_w;
+  const long long hw = (long long)h * w;
+  if (h % 16 != 0 || hw * 32 * 12 >= (1ll << 31)) return SR_OK;
+  for (int k = 0; k < 5; ++k) {
+    const sr_conv3x3_desc& c = d[k];
+    if (c.in != d[0].in || c.in_img_stride != d[0].in_img_stride || c.n != n || c.in_h != h || c.in_w != w || c.upsample || c.out_nchw ||
+        c.s2_channels != 0 || c.cin_pad != 64 + 32 * k || c.cout != (k < 4 ? 32 : 64) || c.accumulate)
+      return SR_OK;
+    if (k < 4 && ((const __bf16*)c.out != (const __bf16*)d[0].in + (64 + 32 * k) * hw || c.out_img_stride != d[0].in_img_stride ||
+                  c.res1 || c.res2))
+      return SR_OK;
+  }
+  if (d[0].in_img_stride < 192 * hw) return SR_OK;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SR_OK;
+  static int cu_count[16] = {0};
+  if (dev < 0 || dev >= 16) return SR_OK;
+  if (cu_count[dev] == 0) {
+    auto kern = rdb_fused_bf16_kernel;
+    if (int rc = sr::ensure_dynamic_lds((const void*)kern, fz::LDS_BYTES)) return rc;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, fz::LDS_BYTES) != hipSuccess || per_cu < 1) {
+      cu_count[dev] = -1;
+    } else {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = -1;
+      cu_count[dev] = cus;
+    }
+  }
+  if (cu_count[dev] < 1) return SR_OK;
+  const int conc = sr::launch_concurrency();
+  const int avail = cu_count[dev] / (conc > 1 ? conc : 1);
+  const int tiles_x = sr::cdiv(w, 32), tiles_y = h / 16;
+  const int T = tiles_x * tiles_y;
+  if (T > avail) return SR_OK;  // an image's tiles wait for each other: they must all be resident
+  fz::FusedParams P = {};
+  const char* lo = (const char*)d[0].wpacked;
+  for (int k = 1; k < 5; ++k)
+    if ((const char*)d[k].wpacked < lo) lo = (const char*)d[k].wpacked;
+  unsigned long long span = 0;
+  for (int k = 0; k < 5; ++k) {
+    if (int rc = fill_params_h(&d[k], P.lv[k], "sr_conv3x3_chain_bf16")) return rc;
+    P.lv[k].tiles_x = tiles_x;
+    P.lv[k].tiles_y = tiles_y;
+    P.lv[k].cogs = 1;
+    const unsigned long long dl = (unsigned long long)((const char*)d[k].wpacked - lo);
+    const unsigned long long end = dl + (unsigned long long)(4 + 2 * k) * 9 * (k < 4 ? 1 : 2) * 1024;
+    if (end >= (1ull << 31)) return SR_OK;
+    P.wdelta[k] = (unsigned)dl;
+    if (end > span) span = end;
+  }
+  P.wbase = lo;
+  P.wspan = (unsigned)span;
+  P.n = n;
+  P.ipr = avail / T < n ? avail / T : n;
+  P.tiles_x = tiles_x;
+  P.tiles_y = tiles_y;
+  P.abort = sync;
+  P.done = sync + 1 + SR_CHAIN_EPOCHS;
+  P.epoch = call_index * 8;
+  P.dbg = g_fused_clocks;
+  hipLaunchKernelGGL(rdb_fused_bf16_kernel, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  SR_CHECK_LAUNCH("rdb_fused_bf16 launch");
+  *launched = true;
+  return SR_OK;
+}
+
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
+  if (g_chain_enabled == 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS && !sr::prof_on()) {
+    bool launched = false;
+    if (int rc = try_fused_dense_block(d, sync, call_index, stream, &launched)) return rc;
+    if (launched) return SR_OK;
+  }
   // eligibility of the one-launch form: one tile grid (same n, H, W, no upsampling), CB16 outputs, <= 64 couts, 16-row tiles,
   // enough tiles to fill the chip; anything else runs conv by conv (same results)
-  const bool tall = g_chain_enabled != 2;
+  const bool tall = g_chain_enabled == 1;
   const int rows = tall ? 32 : 16;
   bool one_launch = g_chain_enabled && sync && nconv >= 2 && nconv <= SR_CHAIN_MAX && call_index >= 0 && call_index < SR_CHAIN_EPOCHS &&
                     !sr::prof_on();

@@ -3,7 +3,9 @@ hand-offs, against the same convs launched one by one (sr_conv3x3_bf16).  Both r
 same order, so the results must be BIT-identical; what the test probes is the hand-off (write-through stores, agent-scope flags,
 acquire before the dependent loads) — a stale or early read shows up as a difference.  Shapes cover the one-launch path (>= 256
 tiles of 32x32), batches with more tiles than resident workgroups, ragged widths, repeated calls on one sync block (increasing
-call_index) and the fallbacks (small launches, ragged heights), and a run under uneven load from a second stream."""
+call_index) and the fallbacks (small launches, ragged heights), and a run under uneven load from a second stream.
+Mode 3 is the fused dense-block kernel (rdb_fused_bf16_kernel: one workgroup per tile for the whole block, partial sums of all
+unfinished convs in registers, neighbour hand-offs at every conv); shapes it does not take fall back to mode 2 inside the entry point."""
 import pytest
 import torch
 
@@ -58,8 +60,10 @@ def _fresh(dev, n, nf, gc, h, w, seed):
     (64, 64, 64, 32, 32),      # nf = 32: all five convs on the 32-cout tile
     (2, 64, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
     (12, 120, 128, 64, 32),    # height not a multiple of 32: fallback
+    (20, 128, 128, 64, 32),    # fused kernel: three rounds of 8 images, the last one partly empty
+    (5, 208, 96, 64, 32),      # fused kernel: 39 tiles per image, 6 images per round
 ])
-@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('mode', [1, 2, 3])
 def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
     _lib.check(_lib.load().sr_set_conv_chain(mode), 'sr_set_conv_chain')
     packs = _rdb(cuda, nf, gc, 3)
@@ -79,7 +83,7 @@ def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
     assert bool(torch.isfinite(nxt_b.buf[:, :nf // 16].float()).all())
 
 
-@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('mode', [1, 2, 3])
 def test_chain_under_uneven_load_and_with_rrdb_residuals(cuda, mode):
     """Three chained dense blocks = one RRDB (the third closes with the RRDB residual, rrdbnet_arch.py:58-63) while a second stream
     keeps part of the chip busy with unrelated bandwidth-heavy work: hand-offs must hold when workgroups are delayed unevenly."""
