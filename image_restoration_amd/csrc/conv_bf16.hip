@@ -67,7 +67,9 @@ __device__ __forceinline__ void glds16h(const void* src, char* lds_dst) {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(void* ptr, u32x4_t v, bool write_through) {
   if (write_through)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory");
+    // + two wait states: a 16-byte store reads its data registers after it has issued, and behind an asm the compiler does not
+    // know that the next vector instruction must not overwrite them yet (the VMEM store-data hazard)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
   else
     *(__attribute__((address_space(1))) u32x4_t*)ptr = v;  // global, also where the pointer's origin is opaque (conv_params)
 }
@@ -796,13 +798,16 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 namespace fz {
 constexpr int NW = 8, PT = 2, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
 constexpr int XU = 20, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer (18 x 34 pixels x 32 B, rounded up)
-constexpr int RING = 32;                            // weight ring, pieces
-constexpr int LDS_W0 = NTB * XBUF;
-constexpr int LDS_FLAGS = LDS_W0 + RING * 1024;     // 64 words: neighbour progress words land here
+constexpr int RING = 36;                            // weight ring, pieces
+constexpr int LDS_W0 = 0;                           // the ring first: its reads then need no address arithmetic (16-bit offsets)
+constexpr int LDS_X0 = RING * 1024;                 // tile buffers
+constexpr int LDS_FLAGS = LDS_X0 + NTB * XBUF;      // 64 words: neighbour progress words land here
 constexpr int LDS_BIAS = LDS_FLAGS + 256;           // 5 x 64 floats
-constexpr int LDS_BYTES = LDS_BIAS + 5 * 64 * 4;
+constexpr int LDS_WTAB = LDS_BIAS + 5 * 64 * 4;     // source offset of every weight piece (480 words)
+constexpr int LDS_BYTES = LDS_WTAB + 480 * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "fused dense block: LDS");
 constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
-constexpr int MAXSTEPS = 80, MAXP = 512;
+constexpr int MAXSTEPS = 80, MAXP = 480;
 constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
 
 struct StepD {
@@ -817,6 +822,8 @@ struct StepD {
   int Kflag;        // tile_in > 0: instructions younger than that flag fetch
   int zero_mask;    // accumulator groups that start with this step
   int first_of_in;  // > 0: first step that reads input group first_of_in
+  int uc0, dc0;     // units / tap columns before this step (parities select the operand registers)
+  int pre;          // the operands of this step's first unit were read during the previous step
 };
 struct Sched {
   int nsteps, npieces, ngroups, q_init, ok;
@@ -843,9 +850,9 @@ constexpr int in_chunks(int s) { return s == 0 ? 4 : 2; }
 constexpr int in_cb0(int s) { return s == 0 ? 0 : 4 + 2 * (s - 1); }
 constexpr int in_tb0(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 0 : s == 3 ? 2 : 4; }
 
-constexpr Sched make_sched() {
+constexpr Sched make_sched(const bool lean) {
   Sched s{};
-  int ns = 0, np = 0, seen = 0;
+  int ns = 0, np = 0, seen = 0, uc = 0, dc = 0;
   int post_step[6] = {-1, -1, -1, -1, -1, -1}, first_use[5] = {-1, -1, -1, -1, -1};
   for (int ph = 0; ph < kNPhase; ++ph) {
     const int in = kPhase[ph][0], g0 = kPhase[ph][3], ng = kPhase[ph][4], perdx = kPhase[ph][5];
@@ -861,6 +868,10 @@ constexpr Sched make_sched() {
         d.tb = in_tb0(in) + c;
         d.wp0 = np;
         d.wpn = d.ndx * ng * 3;
+        d.uc0 = uc;
+        d.dc0 = dc;
+        uc += d.ndx * ng;
+        dc += d.ndx;
         for (int j = 0; j < d.wpn; ++j) {
           const int dx = d.dx0 + j / (ng * 3), g = g0 + (j / 3) % ng, dy = j % 3;
           const int k = g < 4 ? g : 4, cot = g < 4 ? 1 : 2, cc = g < 4 ? 0 : g - 4;
@@ -886,6 +897,7 @@ constexpr Sched make_sched() {
   }
   s.nsteps = ns;
   s.npieces = np;
+  for (int i = 1; i < ns; ++i) s.st[i].pre = s.st[i - 1].post ? 0 : 1;  // not across an epilogue (register pressure)
   while (np % 8) {  // whole groups of eight: the padding re-loads piece 0 into a free slot
     s.wtab[np] = s.wtab[0];
     ++np;
@@ -896,7 +908,7 @@ constexpr Sched make_sched() {
   for (int j = 0; j < ns; ++j) last_use[s.st[j].in] = j;
   for (int t = 1; t <= 4; ++t) {  // conv t -> input group t
     const int pub = post_step[t] + kPubLag[t - 1], ti = pub + kTileLag[t - 1], tf = ti - kFlagLead[t - 1];
-    if (post_step[t] < 0 || tf <= pub || ti >= first_use[t]) s.ok = 0;
+    if (post_step[t] < 0 || tf <= pub || ti >= first_use[t] - 1) s.ok = 0;
     s.st[pub].publish = t;
     s.st[ti].tile_in = t;
     s.st[tf].flag_in = t;
@@ -915,15 +927,21 @@ constexpr Sched make_sched() {
   tend[0][0] = seq;
   seq += 5;  // chunks 2-3
   tend[0][1] = seq;
-  int issued = RING / 8;
+  int issued = RING / 8;  // whole groups that fit the empty ring
   s.q_init = issued;
   for (int q = 0; q < issued; ++q) gend[q] = ++seq;
   for (int i = 0; i < ns; ++i) {
     StepD& d = s.st[i];
-    const int qn = (d.wp0 + d.wpn - 1) / 8;
-    const int te = tend[d.in][d.chunk / 2];
-    if (gend[qn] == 0 || te == 0 || d.wpn > RING) s.ok = 0;
-    int need = gend[qn] > te ? gend[qn] : te;
+    // the barrier of step i says: the operands of steps i and i+1 have landed (step i+1's first reads are issued during step i)
+    int need = 0;
+    for (int j = i; j <= i + 1 && j < ns; ++j) {
+      const StepD& dj = s.st[j];
+      const int qn = (dj.wp0 + dj.wpn - 1) / 8;
+      const int te = tend[dj.in][dj.chunk / 2];
+      if (gend[qn] == 0 || te == 0 || dj.wpn > RING) s.ok = 0;
+      if (gend[qn] > need) need = gend[qn];
+      if (te > need) need = te;
+    }
     if (d.publish) {
       if (send[d.publish] == 0) s.ok = 0;
       if (send[d.publish] > need) need = send[d.publish];
@@ -940,6 +958,7 @@ constexpr Sched make_sched() {
     d.q1 = q1;
     for (int q = issued; q < q1; ++q) gend[q] = ++seq;
     issued = q1;
+    if (lean && d.first_of_in == 4) seq += 16;  // LEAN kernel: conv5's residual sources are fetched here
     if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
     if (d.post >= 1 && d.post <= 4) {
       seq += 4;  // the epilogue's stores: 2 rows x 2 channel blocks
@@ -950,8 +969,8 @@ constexpr Sched make_sched() {
   if (issued != s.ngroups) s.ok = 0;
   return s;
 }
-constexpr Sched kS = make_sched();
-static_assert(kS.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
+constexpr Sched kS = make_sched(false), kSL = make_sched(true);  // they differ in K / Kflag only
+static_assert(kS.ok == 1 && kSL.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
 struct WTab {
   unsigned v[MAXP];
 };
@@ -972,11 +991,24 @@ struct FusedParams {
   int* abort;
   int epoch;
   long long* dbg;
+  // LEAN kernel (the forward dense block: conv1-4 = bias + LeakyReLU(slope), conv5 = alpha5 (conv + bias) + beta1 res1 [+ beta2 res2])
+  float slope, alpha5, beta1, beta2;
+  char* out5;  // conv5's destination, residual sources: CB16 tensors of 64 channels over the same pixel grid
+  const char* res1;
+  const char* res2;  // may be null
+  long long out5_nb, res1_nb, res2_nb;
 };
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+
+#ifndef SR_FZ_DRAIN
+#define SR_FZ_DRAIN 0  // development: 1 = every counted wait becomes vmcnt(0)
+#endif
 template <int K>
 __device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR_FZ_DRAIN ? 0 : K) : "memory");
 }
 
 typedef __attribute__((address_space(3))) int* lds_int_p;
@@ -985,16 +1017,16 @@ typedef __attribute__((address_space(3))) void* lds_void_p;
 struct Env {
   char* smem;
   lds_int_p ctl;       // LDS word: a dependency wait timed out
-  int lane, wave, tid;
-  int n, tile, x, y_first, h;  // image, tile of the batch, this lane's output column, this wave's first row, lane half
+  int wave, tid;
+  int n, tile, x0, y0;  // image, tile of the batch, first column / row of the tile
   unsigned xvo[5];     // lane offsets of this wave's five tile pieces (per pair of chunks)
   unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
   unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
-  unsigned T[8];       // lane l of T[m]: source offset of weight piece 64 m + l
   unsigned plane_b;
+  int W;               // image width
+  const char* xin;     // the image's concat buffer
   int xl[3];           // LDS byte offset of this lane's pixel operand at tap column dx (tile row of the wave)
   int wlane;           // LDS byte offset of this lane's weight operand inside a piece
-  const int* flag_ptr; // lanes 0-8 of wave 0: progress word of a neighbour tile (null: outside the image)
   long long* dbg;
 };
 
@@ -1004,15 +1036,18 @@ __device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buf
   for (int r = 0; r < 5; ++r) {
     const int u = r * NW + e.wave;
     const int ci = u >= XU ? 1 : 0, pc = u - ci * XU;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + (tb0 + ci) * XBUF + pc * 1024), 16, e.xvo[r],
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, e.xvo[r],
                                              (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
   }
 }
 
 template <int Q>
 __device__ __forceinline__ void issue_wgroup(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
-  const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)e.T[Q / 8], (Q % 8) * 8 + e.wave);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_p)(e.smem + LDS_W0 + (((Q * 8) % RING) + e.wave) * 1024), 16, e.wvo, so, 0, 0);
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(*(const lds_int_p)(e.smem + LDS_WTAB + (Q * 8 + e.wave) * 4));
+  constexpr int base = (Q * 8) % RING;
+  int slot = base + e.wave;
+  if constexpr (base + 7 >= RING) slot = slot >= RING ? slot - RING : slot;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_p)(e.smem + LDS_W0 + slot * 1024), 16, e.wvo, so, 0, 0);
 }
 template <int Q, int Q1>
 __device__ __forceinline__ void issue_wgroups(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
@@ -1022,38 +1057,59 @@ __device__ __forceinline__ void issue_wgroups(const Env& e, const __amdgpu_buffe
   }
 }
 
-// the MFMAs of step S: units (tap column, group) in order, the operands of the next unit read before this unit's MFMAs
+// the MFMAs of step S: units (tap column, group) in order, three weight fragments (tap rows) per unit.  Operands are read ahead of
+// their MFMAs — weight fragments AR-1 fragments ahead through a ring of AR, the pixel rows of the next tap column during the current
+// column's last unit — and the read-ahead runs across the step barrier: the barrier then meets waves whose next MFMAs can issue at once
+// (the barrier of step S-1 has already said that step S's weight pieces and tile have landed).
+constexpr int AR = 4;
+struct Ops {
+  bf16x8 bx[2][PT + 2];  // pixel operands of a tap column, by parity of the column count
+  bf16x8 a[AR];          // weight fragments, by fragment count modulo AR
+};
 template <int S>
-__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT]) {
+__device__ __forceinline__ void load_bx(const Env& e, Ops& o, const int dxi) {  // tap column dx0 + dxi of step S
   constexpr StepD d = kS.st[S];
-  constexpr int NU = d.ndx * d.ng;
-  bf16x8 bx[2][PT + 2], a[2][3];
-  const char* xb = e.smem + d.tb * XBUF;
-  const char* wb = e.smem + LDS_W0 + e.wlane;
-  auto ld_bx = [&](int slot, int dx) {
+  const char* xs = e.smem + LDS_X0 + d.tb * XBUF + e.xl[d.dx0 + dxi];
 #pragma unroll
-    for (int r = 0; r < PT + 2; ++r) bx[slot][r] = *(const bf16x8*)(xb + e.xl[dx] + r * XROW * 32);
-  };
-  auto ld_a = [&](int slot, int u) {
+  for (int r = 0; r < PT + 2; ++r) o.bx[(d.dc0 + dxi) & 1][r] = *(const bf16x8*)(xs + r * XROW * 32);
+}
+template <int S>
+__device__ __forceinline__ void load_a(const Env& e, Ops& o, const int lf) {  // fragment lf = 3 unit + tap row of step S
+  constexpr StepD d = kS.st[S];
+  o.a[(3 * d.uc0 + lf) % AR] = *(const bf16x8*)(e.smem + LDS_W0 + e.wlane + ((d.wp0 + lf) % RING) * 1024);
+}
+template <int S>
+__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT], Ops& o) {
+  constexpr StepD d = kS.st[S];
+  constexpr int NU = d.ndx * d.ng, NF = 3 * NU;
+  constexpr bool next_pre = S + 1 < kS.nsteps && kS.st[S + 1 < kS.nsteps ? S + 1 : S].pre;
+  if constexpr (!d.pre) {
+    load_bx<S>(e, o, 0);
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) a[slot][dy] = *(const bf16x8*)(wb + ((d.wp0 + u * 3 + dy) % RING) * 1024);
-  };
-  ld_bx(0, d.dx0);
-  ld_a(0, 0);
+    for (int f = 0; f < AR - 1; ++f) load_a<S>(e, o, f);
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int dxi = u / d.ng, g = d.g0 + u % d.ng;
-    if (u + 1 < NU) {
-      if ((u + 1) % d.ng == 0) ld_bx((dxi + 1) & 1, d.dx0 + dxi + 1);
-      ld_a((u + 1) & 1, u + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int dy = 0; dy < 3; ++dy) {
+      const int lf = 3 * u + dy, nf = lf + AR - 1;
+      if (nf < NF)
+        load_a<S>(e, o, nf);
+      else if constexpr (next_pre)
+        load_a<(next_pre ? S + 1 : S)>(e, o, nf - NF);
+      if (dy == 0 && (u + 1) % d.ng == 0) {  // last unit of this tap column: the next column's pixel rows
+        if (u + 1 < NU)
+          load_bx<S>(e, o, dxi + 1);
+        else if constexpr (next_pre)
+          load_bx<(next_pre ? S + 1 : S)>(e, o, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < PT; ++r)
-        acc[g][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 1][dy], bx[dxi & 1][r + dy], acc[g][r], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+        acc[g][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[(3 * d.uc0 + lf) % AR], o.bx[(d.dc0 + dxi) & 1][r + dy], acc[g][r], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -1074,27 +1130,144 @@ __device__ __forceinline__ ConvParamsH conv_params(int k) {
   return r;
 }
 
+// ---- epilogues of the LEAN (forward) kernel: one basic block each, no vector-memory loads.  Per element the operations and their
+// order are those of epilogue_cb16 (bias add, LeakyReLU, scale, residual scale-adds, bf16 conversion), with two exact shortcuts:
+// LeakyReLU as max(v, v * slope) for 0 <= slope <= 1 (the same value for every input, signed zeros and NaNs included) and no
+// multiplication by a scale of exactly 1.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swap_halves4(u32x4v& t) {  // t[0..1] of the upper lanes <-> t[2..3] of the lower lanes
+  auto r0 = __builtin_amdgcn_permlane32_swap(t[0], t[2], false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(t[1], t[3], false, false);
+  t = u32x4v{r0[0], r1[0], r0[1], r1[1]};
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ unsigned tile_lane_offset(const Env& e) {  // byte offset of (first row of the wave, this lane's column, half)
+  const int lane = e.tid & 63, x = e.x0 + (lane & 31);
+  return x < e.W ? (unsigned)(((e.y0 + e.wave * PT) * e.W + x) * 32 + (lane >> 5) * 16) : 0xfffffff0u;
+}
+
+template <int K>  // conv K+1, K = 0..3: x_(K+1) = LeakyReLU(acc + bias) into blocks 4+2K, 5+2K of the concat buffer, write-through
+__device__ __forceinline__ void epi_mid_lean(const Env& e, f32x16 (&acc)[PT], const __amdgpu_buffer_rsrc_t x_rs, const float slope) {
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
+  const int h = (e.tid >> 5) & 1;
+  f32x4 bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bias[g] = *(lds_f4_p)(e.smem + LDS_BIAS + K * 256 + (g * 8 + h * 4) * 4);
+  const unsigned vo = tile_lane_offset(e);
+#pragma unroll
+  for (int r = 0; r < PT; ++r)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = acc[r][m * 8 + i] + bias[2 * m + (i >> 2)][i & 3];
+        v[i] = __builtin_fmaxf(t, t * slope);
+      }
+      u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      swap_halves4(o);
+      // a global store behind store16's asm (store + two wait states): as a buffer store with a scalar offset — the form the
+      // compiler's hazard recognizer treats as safe — the next vector instruction overwrote the store's first data register in
+      // ~1 of 500 tiles (second wave of a SIMD; measured)
+      if (vo != 0xfffffff0u) store16((char*)e.xin + (size_t)(4 + 2 * K + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, true);
+    }
+}
+
+struct ResRegs {
+  u32x4v r1[2][PT][2], r2[2][PT][2];  // [cout tile][row][channel block]: the residual sources of conv5's epilogue, fetched ahead
+};
+__device__ __forceinline__ void fetch_residuals(const Env& e, ResRegs& R, const __amdgpu_buffer_rsrc_t r1_rs, const __amdgpu_buffer_rsrc_t r2_rs) {
+  const unsigned vo = tile_lane_offset(e);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < PT; ++r)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const unsigned v = vo == 0xfffffff0u ? vo : vo + (unsigned)(r * e.W * 32);
+        R.r1[c][r][m] = __builtin_amdgcn_raw_buffer_load_b128(r1_rs, v, (unsigned)(c * 2 + m) * e.plane_b, 0);
+        R.r2[c][r][m] = __builtin_amdgcn_raw_buffer_load_b128(r2_rs, v, (unsigned)(c * 2 + m) * e.plane_b, 0);  // empty descriptor: zeros
+      }
+}
+// conv5: out = alpha (acc + bias) + beta1 res1 [+ beta2 res2]
+__device__ __forceinline__ void epi_last_lean(const Env& e, f32x16 (&acc)[2][PT], ResRegs& R, char* out, const float alpha,
+                                              const float beta1, const float beta2, const bool has_res2) {
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
+  const int h = (e.tid >> 5) & 1;
+  const unsigned vo = tile_lane_offset(e);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *(lds_f4_p)(e.smem + LDS_BIAS + 4 * 256 + (c * 32 + g * 8 + h * 4) * 4);
+#pragma unroll
+    for (int r = 0; r < PT; ++r)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        u32x4v a = R.r1[c][r][m], b = R.r2[c][r][m];
+        swap_halves4(a);
+        swap_halves4(b);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = (acc[c][r][m * 8 + i] + bias[2 * m + (i >> 2)][i & 3]) * alpha;
+          const unsigned wa = a[i >> 1], wb = b[i >> 1];
+          t += beta1 * __builtin_bit_cast(float, (i & 1) ? (wa & 0xffff0000u) : (wa << 16));
+          const float t2 = t + beta2 * __builtin_bit_cast(float, (i & 1) ? (wb & 0xffff0000u) : (wb << 16));
+          v[i] = has_res2 ? t2 : t;
+        }
+        u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        swap_halves4(o);
+        if (vo != 0xfffffff0u) store16(out + (size_t)(c * 2 + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, false);
+      }
+  }
+}
+
+// the LEAN kernel's scalars, read from the kernel argument segment where they are used (see conv_params)
+template <class T>
+__device__ __forceinline__ T kernarg_at(unsigned off) {
+  asm volatile("" : "+s"(off));
+  typedef const __attribute__((address_space(4))) unsigned* kernarg_words;
+  kernarg_words src = (kernarg_words)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  static_assert(sizeof(T) % 4 == 0, "copied word by word");
+  unsigned words[sizeof(T) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) words[i] = src[i];
+  T r;
+  __builtin_memcpy(&r, words, sizeof(r));
+  return r;
+}
+
 __device__ __forceinline__ void stamp(const Env& e, int i) {
   if (e.dbg && e.tid == 0) e.dbg[i] = __builtin_readcyclecounter();
 }
 
-template <int S>
-__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+template <int S, bool LEAN>
+__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
                                         const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
   constexpr StepD d = kS.st[S];
+  // the lane address bases pass through an empty asm at every step: derived addresses (tile buffer + column offset ...) are then
+  // computed where they are used instead of being hoisted out of the round loop into two dozen permanently live registers
+  asm volatile("" : "+v"(e.xl[0]), "+v"(e.xl[1]), "+v"(e.xl[2]), "+v"(e.wlane));
   if constexpr (d.publish > 0) stamp(e, 2 + 8 * (d.publish - 1) + 2);
   if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 6);
   if constexpr (d.tile_in > 0) {  // the neighbours' conv `tile_in` must be published before its tile is fetched
     stamp(e, 2 + 8 * (d.tile_in - 1) + 4);
     if (e.wave == 0) {
-      wait_vm<d.Kflag>();  // the flag fetch of a few steps ago has landed
+      wait_vm<(LEAN ? kSL.st[S].Kflag : d.Kflag)>();  // the flag fetch of a few steps ago has landed
       bool gave_up = false;
-      if (e.flag_ptr) {
+      const int lane = e.tid & 63;
+      if (e.fvo != 0xfffffff0u) {
         const int want = P.epoch + d.tile_in;
-        int v = *(volatile lds_int_p)(e.smem + LDS_FLAGS + e.lane * 4), spins = 0;
+        const int* flag_ptr = P.done + e.n * (P.tiles_x * P.tiles_y) + (e.fvo >> 2);
+        int v = *(volatile lds_int_p)(e.smem + LDS_FLAGS + lane * 4), spins = 0;
         while (v < want) {
           __builtin_amdgcn_s_sleep(2);
-          v = flag_load(e.flag_ptr);
+          v = flag_load(flag_ptr);
           if ((++spins & 255) == 0 && (spins > (1 << 22) || flag_load(P.abort))) {
             __hip_atomic_store(P.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gave_up = true;
@@ -1103,12 +1276,12 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], const Fus
         }
       }
       if (__builtin_amdgcn_ballot_w64(gave_up)) {
-        if (e.lane == 0) *(volatile lds_int_p)e.ctl = 1;
+        if (lane == 0) *(volatile lds_int_p)e.ctl = 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
   }
-  wait_vm<d.K>();
+  wait_vm<(LEAN ? kSL.st[S].K : d.K)>();
   __builtin_amdgcn_s_barrier();
   if constexpr (S == 0) stamp(e, 1);
   if constexpr (d.tile_in > 0) stamp(e, 2 + 8 * (d.tile_in - 1) + 5);
@@ -1125,6 +1298,14 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], const Fus
   if constexpr (d.flag_in > 0) {
     if (e.wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
   }
+  if constexpr (LEAN && d.first_of_in == 4) {  // conv5's residual sources: 16 loads per wave that land under the last input's MFMAs
+    const char* r1 = kernarg_at<const char*>(offsetof(FusedParams, res1));
+    const char* r2 = kernarg_at<const char*>(offsetof(FusedParams, res2));
+    const long long nb1 = kernarg_at<long long>(offsetof(FusedParams, res1_nb)), nb2 = kernarg_at<long long>(offsetof(FusedParams, res2_nb));
+    __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
+    fetch_residuals(e, R, make_rsrc(r1 + e.n * nb1, 4u * e.plane_b), make_rsrc(r2 ? r2 + e.n * nb2 : r1, r2 ? 4u * e.plane_b : 0u));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if constexpr (d.post > 0 && d.post < 5) stamp(e, 2 + 8 * (d.post - 1));  // last step of conv `post` runs
   if constexpr (d.post == 5) stamp(e, 40);
 #pragma unroll
@@ -1135,38 +1316,48 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], const Fus
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][r][i] = 0.f;
     }
-  compute_step<S>(e, acc);
+  compute_step<S>(e, acc, o);
   typedef const __attribute__((address_space(3))) float* lds_float_p;
-  if constexpr (d.post > 0 && d.post < 5) {
+  if constexpr (LEAN && d.post > 0 && d.post < 5) {
+    epi_mid_lean<d.post - 1>(e, acc[d.post - 1], x_rs, kernarg_at<float>(offsetof(FusedParams, slope)));
+    stamp(e, 2 + 8 * (d.post - 1) + 1);
+  } else if constexpr (LEAN && d.post == 5) {
+    stamp(e, 41);
+    char* o5 = kernarg_at<char*>(offsetof(FusedParams, out5));
+    const long long nbo = kernarg_at<long long>(offsetof(FusedParams, out5_nb));
+    epi_last_lean(e, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), R, o5 + e.n * nbo,
+                  kernarg_at<float>(offsetof(FusedParams, alpha5)), kernarg_at<float>(offsetof(FusedParams, beta1)),
+                  kernarg_at<float>(offsetof(FusedParams, beta2)), kernarg_at<const char*>(offsetof(FusedParams, res2)) != nullptr);
+  } else if constexpr (d.post > 0 && d.post < 5) {
     const ConvParamsH lp = conv_params(d.post - 1);
-    epilogue_cb16<1, PT, true, true>(lp, reinterpret_cast<f32x16(&)[1][PT]>(acc[d.post - 1]), 0, e.n, e.x, e.y_first, e.h,
+    epilogue_cb16<1, PT, true, true>(lp, reinterpret_cast<f32x16(&)[1][PT]>(acc[d.post - 1]), 0, e.n, e.x0 + (e.tid & 31),
+                                     e.y0 + e.wave * PT, (e.tid >> 5) & 1,
                                      (lds_float_p)(e.smem + LDS_BIAS + (d.post - 1) * 256));
     stamp(e, 2 + 8 * (d.post - 1) + 1);
   } else if constexpr (d.post == 5) {
     stamp(e, 41);
     const ConvParamsH lp = conv_params(4);
-    epilogue_cb16<2, PT, false, true>(lp, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), 0, e.n, e.x, e.y_first, e.h,
+    epilogue_cb16<2, PT, false, true>(lp, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), 0, e.n, e.x0 + (e.tid & 31), e.y0 + e.wave * PT,
+                                      (e.tid >> 5) & 1,
                                       (lds_float_p)(e.smem + LDS_BIAS + 4 * 256));
   }
   return true;
 }
 
-template <int S>
-__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+template <int S, bool LEAN>
+__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
                                           const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
   if constexpr (S < kS.nsteps) {
-    if (!do_step<S>(e, acc, P, x_rs, w_rs, f_rs)) return false;
-    return run_steps<S + 1>(e, acc, P, x_rs, w_rs, f_rs);
+    if (!do_step<S, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs)) return false;
+    return run_steps<S + 1, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs);
   } else {
     return true;
   }
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
 }  // namespace fz
 
+template <bool LEAN>
 __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedParams P) {
   using namespace fz;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1175,24 +1366,23 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   e.smem = smem;
   e.ctl = (lds_int_p)&s_ctl;
   e.tid = threadIdx.x;
-  e.lane = e.tid & 63;
+  const int lane = e.tid & 63;
   e.wave = __builtin_amdgcn_readfirstlane(e.tid >> 6);
   e.dbg = P.dbg ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-  const int j = e.lane & 31;
-  e.h = e.lane >> 5;
+  const int j = lane & 31, h = lane >> 5;
   const ConvParamsH& p0 = P.lv[0];
   e.plane_b = (unsigned)(p0.H * p0.W * 32);
-  e.wvo = (e.lane ^ ((e.lane >> 4) & 1)) * 16;
-  e.wlane = j * 32 + ((e.h ^ ((j >> 3) & 1)) * 16);
+  e.W = p0.W;
+  e.wvo = (lane ^ ((lane >> 4) & 1)) * 16;
+  e.wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);
   const int xrow0 = ((e.wave * PT) * XROW + j) * 32;
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) e.xl[dx] = xrow0 + dx * 32 + ((e.h ^ (((j + dx) >> 3) & 1)) * 16);
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    const unsigned t = kWTabDev.v[m * 64 + e.lane];
+  for (int dx = 0; dx < 3; ++dx) e.xl[dx] = xrow0 + dx * 32 + ((h ^ (((j + dx) >> 3) & 1)) * 16);
+  if (e.tid < 480) {  // source offset of every weight piece: the static table + where this block's five images are
+    const unsigned t = kWTabDev.v[e.tid];
     const unsigned k = t >> 28;
     const unsigned dlt = k == 0 ? P.wdelta[0] : k == 1 ? P.wdelta[1] : k == 2 ? P.wdelta[2] : k == 3 ? P.wdelta[3] : P.wdelta[4];
-    e.T[m] = dlt + (t & 0x0fffffffu);
+    ((unsigned*)(smem + LDS_WTAB))[e.tid] = dlt + (t & 0x0fffffffu);
   }
   const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(P.wbase, P.wspan);
   if (e.tid == 0) s_ctl = 0;
@@ -1206,14 +1396,14 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   int t = blockIdx.x - slot * T;
   const int tx = t % P.tiles_x, ty = t / P.tiles_x;
   const int x0 = tx * 32, y0 = ty * TH;
-  e.x = x0 + j;
-  e.y_first = y0 + e.wave * PT;
+  e.x0 = x0;
+  e.y0 = y0;
   // lane offsets of this wave's tile pieces (they do not depend on the image)
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int u = r * NW + e.wave;
     const int pc = u >= XU ? u - XU : u;
-    const int q = pc * 64 + e.lane;
+    const int q = pc * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
@@ -1222,8 +1412,8 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   }
   // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
   int nb = -1;
-  if (e.wave == 0 && e.lane < 9) {
-    const int ny = ty + e.lane / 3 - 1, nx = tx + e.lane % 3 - 1;
+  if (e.wave == 0 && lane < 9) {
+    const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
     if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) nb = ny * P.tiles_x + nx;
   }
   e.fvo = nb >= 0 ? (unsigned)nb * 4u : 0xfffffff0u;
@@ -1231,8 +1421,8 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     e.n = round * P.ipr + slot;
     if (e.n >= P.n) break;
     e.tile = e.n * T + ty * P.tiles_x + tx;
-    e.flag_ptr = nb >= 0 ? P.done + e.n * T + nb : nullptr;
-    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(p0.in + (long long)e.n * p0.in_nb, 12u * e.plane_b);
+    e.xin = p0.in + (long long)e.n * p0.in_nb;
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(e.xin, 12u * e.plane_b);
     const __amdgpu_buffer_rsrc_t f_rs = make_rsrc(P.done + e.n * T, (unsigned)T * 4u);
     __syncthreads();  // the previous round's LDS reads are over (first round: s_ctl and the biases are set)
     stamp(e, 0);
@@ -1240,7 +1430,9 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     issue_tile_pair<0>(e, x_rs, 2, 2);
     issue_wgroups<0, kS.q_init>(e, w_rs);
     f32x16 acc[NG][PT];
-    if (!run_steps<0>(e, acc, P, x_rs, w_rs, f_rs)) break;
+    Ops o;
+    ResRegs R;
+    if (!run_steps<0, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs)) break;
     stamp(e, 42);
   }
 }
@@ -1383,10 +1575,11 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   static int cu_count[16] = {0};
   if (dev < 0 || dev >= 16) return SR_OK;
   if (cu_count[dev] == 0) {
-    auto kern = rdb_fused_bf16_kernel;
-    if (int rc = sr::ensure_dynamic_lds((const void*)kern, fz::LDS_BYTES)) return rc;
+    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<false>, fz::LDS_BYTES)) return rc;
+    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<true>, fz::LDS_BYTES)) return rc;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, fz::LDS_BYTES) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rdb_fused_bf16_kernel<true>, 512, fz::LDS_BYTES) != hipSuccess ||
+        per_cu < 1) {
       cu_count[dev] = -1;
     } else {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = -1;
@@ -1425,7 +1618,27 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.done = sync + 1 + SR_CHAIN_EPOCHS;
   P.epoch = call_index * 8;
   P.dbg = g_fused_clocks;
-  hipLaunchKernelGGL(rdb_fused_bf16_kernel, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  // the forward block's epilogues in their lean form: conv1-4 = LeakyReLU(conv + bias), conv5 = alpha (conv + bias) + beta1 res1 [+ beta2 res2]
+  bool lean = d[4].bpacked && d[4].act_slope == 1.f && d[4].res1 && !d[4].mask_src && d[4].res1_img_stride >= 64 * hw &&
+              (!d[4].res2 || d[4].res2_img_stride >= 64 * hw) && d[4].out_img_stride >= 64 * hw;
+  for (int k = 0; k < 4 && lean; ++k)
+    lean = d[k].bpacked && d[k].alpha == 1.f && !d[k].mask_src && d[k].act_slope == d[0].act_slope && d[k].act_slope >= 0.f && d[k].act_slope <= 1.f;
+  if (g_chain_enabled == 4) lean = false;  // development: the generic epilogues
+  if (lean) {
+    P.slope = d[0].act_slope;
+    P.alpha5 = d[4].alpha;
+    P.beta1 = d[4].beta1;
+    P.beta2 = d[4].beta2;
+    P.out5 = P.lv[4].out;
+    P.out5_nb = P.lv[4].out_nb;
+    P.res1 = P.lv[4].res1;
+    P.res1_nb = P.lv[4].res1_nb;
+    P.res2 = P.lv[4].res2;
+    P.res2_nb = P.lv[4].res2_nb;
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<true>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  } else {
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<false>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  }
   SR_CHECK_LAUNCH("rdb_fused_bf16 launch");
   *launched = true;
   return SR_OK;
@@ -1434,7 +1647,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
-  if (g_chain_enabled == 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS && !sr::prof_on()) {
+  if (g_chain_enabled >= 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS && !sr::prof_on()) {
     bool launched = false;
     if (int rc = try_fused_dense_block(d, sync, call_index, stream, &launched)) return rc;
     if (launched) return SR_OK;

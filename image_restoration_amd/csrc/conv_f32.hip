@@ -89,7 +89,9 @@ __device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
 // 16-byte store; write-through (sc1) when another workgroup of the same launch will read the tile (chain kernel).
 __device__ __forceinline__ void store16f(float* ptr, f32x4 v, bool write_through) {
   if (write_through)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory");
+    // + two wait states: a 16-byte store reads its data registers after it has issued, and behind an asm the compiler does not
+    // know that the next vector instruction must not overwrite them yet (the VMEM store-data hazard)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
   else
     *(f32x4*)ptr = v;
 }

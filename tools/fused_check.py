@@ -12,16 +12,20 @@ from test_chain_bf16_gpu import _fresh, _rdb, _steps
 dev = torch.device('cuda')
 lib = _lib.load()
 ok = True
-for (n, h, w) in [(8, 128, 128), (16, 128, 128), (3, 64, 64), (12, 160, 100), (20, 128, 128)]:
+MODE = int(os.environ.get('FUSED_MODE', '3'))
+CFGS = [(8, 128, 128), (16, 128, 128), (3, 64, 64), (12, 160, 100), (20, 128, 128), (24, 128, 128), (20, 128, 128)]
+if os.environ.get('STRESS'):
+    CFGS = [(16, 128, 128), (20, 128, 128), (12, 160, 100)] * 4
+for (n, h, w) in CFGS:
     nf, gc = 64, 32
     packs = _rdb(dev, nf, gc, 3)
     cat_a, nxt_a = _fresh(dev, n, nf, gc, h, w, 5)
     lib.sr_set_conv_chain(0)
     for src, pc, out, kw in _steps(cat_a, nxt_a, packs, nf, gc):
         H.conv3x3_bf16(src, pc, out, **kw)
-    lib.sr_set_conv_chain(3)
+    lib.sr_set_conv_chain(MODE)
     sync = None
-    for rep in range(3):
+    for rep in range(4):
         cat_b, nxt_b = _fresh(dev, n, nf, gc, h, w, 5)
         _, sync = H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc), sync, call_index=rep)
         torch.cuda.synchronize()
@@ -32,7 +36,11 @@ for (n, h, w) in [(8, 128, 128), (16, 128, 128), (3, 64, 64), (12, 160, 100), (2
         if not eq_cat:
             d = (cat_a.buf.float() - cat_b.buf.float()).abs()
             per_block = [float(d[:, b].max()) for b in range(d.shape[1])]
-            msg = f' cat max diff per block {per_block}'
+            bad = (cat_a.buf != cat_b.buf) & ~(torch.isnan(cat_a.buf) & torch.isnan(cat_b.buf))
+            idx = bad.nonzero()
+            imgs = sorted(set(idx[:, 0].tolist()))
+            tiles = sorted(set((int(i[0]), int(i[2]) // 16, int(i[3]) // 32) for i in idx[:4000]))[:12]
+            msg = f' cat bad blocks {[b for b in range(d.shape[1]) if not per_block[b] == 0.0]} images {imgs} tiles(img,ty,tx) {tiles}'
         if not eq_out:
             d = (nxt_a.buf[:, :4].float() - nxt_b.buf[:, :4].float()).abs()
             msg += f' out max diff {float(d.max()):.4g} frac {float((d > 0).float().mean()):.4f}'
