@@ -809,6 +809,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "fused dense block: LDS");
 constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
 constexpr int MAXSTEPS = 80, MAXP = 480;
 constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
+constexpr int AR = 4;    // ring of weight fragments in registers: read AR-1 fragments ahead of their MFMAs
 
 struct StepD {
   int in, chunk, g0, ng, dx0, ndx, tb;
@@ -824,9 +825,11 @@ struct StepD {
   int first_of_in;  // > 0: first step that reads input group first_of_in
   int uc0, dc0;     // units / tap columns before this step (parities select the operand registers)
   int pre;          // the operands of this step's first unit were read during the previous step
+  int nx_tile;      // 1 / 2: the next round's x chunks 0-1 / 2-3 are issued after the step's barrier (their buffers are free)
+  int nx_q0, nx_q1; // the next round's weight piece groups [nx_q0, nx_q1) are issued after the step's barrier
 };
 struct Sched {
-  int nsteps, npieces, ngroups, q_init, ok;
+  int nsteps, npieces, ngroups, q_init, q_ahead, ok;  // q_ahead: groups of the next round issued during a round (the rest, up to q_init, at its start)
   StepD st[MAXSTEPS];
   unsigned wtab[MAXP];  // per piece: conv (4 bits) << 28 | byte offset inside that conv's packed image
 };
@@ -921,6 +924,37 @@ constexpr Sched make_sched(const bool lean) {
       if (same_buf && s.st[j].in != t && j >= issue_step[t] && j <= last_use[t]) s.ok = 0;  // somebody else reads it while t owns it
       if (same_buf && s.st[j].in == t && j < issue_step[t]) s.ok = 0;
     }
+  // read-ahead for the next round (always issued; behind the last round it fetches nothing useful): x chunks as soon as their
+  // buffers hold nothing that is still read, the first weight groups as soon as their ring slots do
+  {
+    int last01 = 0, last23 = 0;
+    for (int j = 0; j < ns; ++j) {
+      if (s.st[j].tb <= 1) last01 = j;
+      if (s.st[j].tb == 2 || s.st[j].tb == 3) last23 = j;
+    }
+    if (last01 + 1 >= ns || last23 + 1 >= ns || last01 >= last23) s.ok = 0;
+    s.st[last01 + 1].nx_tile = 1;
+    s.st[last23 + 1].nx_tile = 2;
+    const int total = s.ngroups * 8;
+    int k = 0;
+    for (int i = 0; i < ns && k < RING / 8; ++i) {
+      s.st[i].nx_q0 = s.st[i].nx_q1 = k;
+      for (;;) {  // group k = slots [8k, 8k+8): free once their last occupants of this round are consumed (read by a step < i)
+        if (k >= RING / 8) break;
+        bool free_now = true;
+        for (int j = 8 * k; j < 8 * k + 8; ++j) {
+          const int occ = j + RING * ((total - 1 - j) / RING);
+          if (occ < s.npieces && occ >= s.st[i].wp0) free_now = false;
+          // the slot's occupant must also have been ISSUED before this barrier (its DMA is then older than the new one)
+          if (occ >= s.st[i].wp0 + RING - 7) free_now = false;
+        }
+        if (!free_now) break;
+        ++k;
+      }
+      s.st[i].nx_q1 = k;
+    }
+    s.q_ahead = k;
+  }
   // the issue sequence of one wave: what is younger than the operations a step needs may stay in flight at its wait
   int seq = 0, gend[MAXP / 8] = {}, tend[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, send[5] = {0, 0, 0, 0, 0}, fseq[5] = {0, 0, 0, 0, 0};
   seq += 5;  // chunks 0-1 of x: 40 pieces = 5 per wave
@@ -932,13 +966,14 @@ constexpr Sched make_sched(const bool lean) {
   for (int q = 0; q < issued; ++q) gend[q] = ++seq;
   for (int i = 0; i < ns; ++i) {
     StepD& d = s.st[i];
-    // the barrier of step i says: the operands of steps i and i+1 have landed (step i+1's first reads are issued during step i)
+    // the barrier of step i says: step i's operands have landed, and so have those that step i reads ahead for step i+1 — its tile and
+    // its first AR-1 weight fragments
     int need = 0;
     for (int j = i; j <= i + 1 && j < ns; ++j) {
       const StepD& dj = s.st[j];
-      const int qn = (dj.wp0 + dj.wpn - 1) / 8;
+      const int qn = (j == i ? dj.wp0 + dj.wpn - 1 : dj.wp0 + AR - 2) / 8;
       const int te = tend[dj.in][dj.chunk / 2];
-      if (gend[qn] == 0 || te == 0 || dj.wpn > RING) s.ok = 0;
+      if (gend[qn] == 0 || te == 0 || dj.wpn > RING || dj.wpn < AR - 1) s.ok = 0;
       if (gend[qn] > need) need = gend[qn];
       if (te > need) need = te;
     }
@@ -958,6 +993,8 @@ constexpr Sched make_sched(const bool lean) {
     d.q1 = q1;
     for (int q = issued; q < q1; ++q) gend[q] = ++seq;
     issued = q1;
+    if (d.nx_tile) seq += 5;
+    seq += d.nx_q1 - d.nx_q0;
     if (lean && d.first_of_in == 4) seq += 16;  // LEAN kernel: conv5's residual sources are fetched here
     if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
     if (d.post >= 1 && d.post <= 4) {
@@ -1061,7 +1098,6 @@ __device__ __forceinline__ void issue_wgroups(const Env& e, const __amdgpu_buffe
 // their MFMAs — weight fragments AR-1 fragments ahead through a ring of AR, the pixel rows of the next tap column during the current
 // column's last unit — and the read-ahead runs across the step barrier: the barrier then meets waves whose next MFMAs can issue at once
 // (the barrier of step S-1 has already said that step S's weight pieces and tile have landed).
-constexpr int AR = 4;
 struct Ops {
   bf16x8 bx[2][PT + 2];  // pixel operands of a tap column, by parity of the column count
   bf16x8 a[AR];          // weight fragments, by fragment count modulo AR
@@ -1248,7 +1284,7 @@ __device__ __forceinline__ void stamp(const Env& e, int i) {
 
 template <int S, bool LEAN>
 __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                        const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
+                                        const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
   constexpr StepD d = kS.st[S];
   // the lane address bases pass through an empty asm at every step: derived addresses (tile buffer + column offset ...) are then
   // computed where they are used instead of being hoisted out of the round loop into two dozen permanently live registers
@@ -1295,6 +1331,8 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
     issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in));  // agent scope: written by other workgroups of this launch
   }
   issue_wgroups<d.q0, d.q1>(e, w_rs);
+  if constexpr (d.nx_tile > 0) issue_tile_pair<0>(e, nx_rs, 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1));
+  issue_wgroups<d.nx_q0, d.nx_q1>(e, w_rs);
   if constexpr (d.flag_in > 0) {
     if (e.wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
   }
@@ -1346,10 +1384,10 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
 
 template <int S, bool LEAN>
 __device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                          const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs) {
+                                          const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
   if constexpr (S < kS.nsteps) {
-    if (!do_step<S, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs)) return false;
-    return run_steps<S + 1, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs);
+    if (!do_step<S, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs)) return false;
+    return run_steps<S + 1, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs);
   } else {
     return true;
   }
@@ -1424,17 +1462,25 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     e.xin = p0.in + (long long)e.n * p0.in_nb;
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(e.xin, 12u * e.plane_b);
     const __amdgpu_buffer_rsrc_t f_rs = make_rsrc(P.done + e.n * T, (unsigned)T * 4u);
-    __syncthreads();  // the previous round's LDS reads are over (first round: s_ctl and the biases are set)
+    // the x tile and the first weight groups of a round are issued during the previous round (make_sched: nx_tile, nx_q*); behind the
+    // last image the descriptor is empty (zeros, no traffic).  Same instructions in the same order before the first round.
+    const bool more = e.n + P.ipr < P.n;
+    const __amdgpu_buffer_rsrc_t nx_rs = make_rsrc(p0.in + (long long)(more ? e.n + P.ipr : 0) * p0.in_nb, more ? 12u * e.plane_b : 0u);
+    if (round == 0) {
+      __syncthreads();  // s_ctl, the biases and the weight-offset table are set
+      issue_tile_pair<0>(e, x_rs, 0, 0);
+      issue_tile_pair<0>(e, x_rs, 2, 2);
+      issue_wgroups<0, kS.q_ahead>(e, w_rs);
+    }
     stamp(e, 0);
-    issue_tile_pair<0>(e, x_rs, 0, 0);
-    issue_tile_pair<0>(e, x_rs, 2, 2);
-    issue_wgroups<0, kS.q_init>(e, w_rs);
+    issue_wgroups<kS.q_ahead, kS.q_init>(e, w_rs);
     f32x16 acc[NG][PT];
     Ops o;
     ResRegs R;
-    if (!run_steps<0, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs)) break;
+    if (!run_steps<0, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs)) break;
     stamp(e, 42);
   }
+  fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
 }
 
 template <int COT, int PT, int NW>
@@ -1539,7 +1585,7 @@ extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
 // 1502 img/s, mode 2 1541, mode 1 (32-row ring tiles, one workgroup per CU) 1458; a dense block alone 159 -> 147 us at batch 16,
 // 310 -> 272 us at batch 32, 771 -> 664 us on four 544x544 tiler cells.  With two workgroups per CU one's hand-off, prologue and
 // epilogue overlap the other's MFMA loop; the single 32-row workgroup has nothing to overlap them with.
-static int g_chain_enabled = 2;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
+static int g_chain_enabled = 3;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
                                  // 3 = fused dense block (rdb_fused_bf16_kernel) where eligible, else as 2
 static long long* g_chain_clocks = nullptr;
 // Development aid (tools/chain_phase.py; not part of the ABI): per work item, wave 0 writes claim / wait / acquire / tile / drain clocks.
