@@ -846,14 +846,27 @@ constexpr int kPhase[kNPhase][7] = {{0, 0, 4, 0, 1, 0, 1},                      
                                     {3, 0, 2, 3, 1, 0, 4},                                              // conv4 x3
                                     {2, 0, 2, 4, 2, 1, 0}, {3, 0, 2, 4, 2, 1, 0},                       //   conv5 x2 | conv5 x3
                                     {4, 0, 2, 4, 2, 1, 5}};                                             // conv5 x4
-constexpr int kPubLag[4] = {4, 2, 2, 3};    // steps from conv k's epilogue to its publish
-constexpr int kTileLag[4] = {5, 4, 4, 5};   // steps from the publish to the fetch of the dependent tile
-constexpr int kFlagLead[4] = {4, 3, 3, 4};  // the flags are fetched this many steps before they are inspected
+#ifndef SR_FZ_PUBLAG
+#define SR_FZ_PUBLAG {4, 2, 2, 3}
+#define SR_FZ_TILELAG {5, 4, 4, 5}
+#define SR_FZ_FLAGLEAD {4, 3, 3, 4}
+#endif
+constexpr int kPubLag[4] = SR_FZ_PUBLAG;      // steps from conv k's epilogue to its publish
+constexpr int kTileLag[4] = SR_FZ_TILELAG;    // steps from the publish to the fetch of the dependent tile
+constexpr int kFlagLead[4] = SR_FZ_FLAGLEAD;  // the flags are fetched this many steps before they are inspected
 constexpr int in_chunks(int s) { return s == 0 ? 4 : 2; }
 constexpr int in_cb0(int s) { return s == 0 ? 0 : 4 + 2 * (s - 1); }
 constexpr int in_tb0(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 0 : s == 3 ? 2 : 4; }
 
-constexpr Sched make_sched(const bool lean) {
+constexpr int kMaskLead[4] = {1, 0, 1, 1};  // conv2 completes while 160 accumulator registers are live: its mask is fetched last-minute
+constexpr int mask_conv_at(const Sched& s, const int i) {  // the conv (1..4) whose mask is fetched at step i, or 0
+  for (int k = 1; k <= 4; ++k) {
+    const int j = i + kMaskLead[k - 1];
+    if (j < s.nsteps && s.st[j].post == k) return k;
+  }
+  return 0;
+}
+constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean forward, 2 lean transposed block (they differ in K / Kflag only)
   Sched s{};
   int ns = 0, np = 0, seen = 0, uc = 0, dc = 0;
   int post_step[6] = {-1, -1, -1, -1, -1, -1}, first_use[5] = {-1, -1, -1, -1, -1};
@@ -995,7 +1008,8 @@ constexpr Sched make_sched(const bool lean) {
     issued = q1;
     if (d.nx_tile) seq += 5;
     seq += d.nx_q1 - d.nx_q0;
-    if (lean && d.first_of_in == 4) seq += 16;  // LEAN kernel: conv5's residual sources are fetched here
+    if (mode && d.first_of_in == 4) seq += 16;  // lean kernels: conv5's residual sources are fetched here
+    if (mode == 2 && mask_conv_at(s, i)) seq += 4;  // ... and conv k's mask kMaskLead steps before its epilogue
     if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
     if (d.post >= 1 && d.post <= 4) {
       seq += 4;  // the epilogue's stores: 2 rows x 2 channel blocks
@@ -1006,8 +1020,12 @@ constexpr Sched make_sched(const bool lean) {
   if (issued != s.ngroups) s.ok = 0;
   return s;
 }
-constexpr Sched kS = make_sched(false), kSL = make_sched(true);  // they differ in K / Kflag only
-static_assert(kS.ok == 1 && kSL.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
+constexpr Sched kS = make_sched(0), kSL = make_sched(1), kSB = make_sched(2);
+static_assert(kS.ok == 1 && kSL.ok == 1 && kSB.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
+template <int MODE, int S>
+constexpr int step_K() { return MODE == 0 ? kS.st[S].K : MODE == 1 ? kSL.st[S].K : kSB.st[S].K; }
+template <int MODE, int S>
+constexpr int step_Kflag() { return MODE == 0 ? kS.st[S].Kflag : MODE == 1 ? kSL.st[S].Kflag : kSB.st[S].Kflag; }
 struct WTab {
   unsigned v[MAXP];
 };
@@ -1034,6 +1052,10 @@ struct FusedParams {
   const char* res1;
   const char* res2;  // may be null
   long long out5_nb, res1_nb, res2_nb;
+  // lean transposed block: conv1-4 = lrelu'(mask) * conv (mask: the forward activation, 32 channels), conv5 as above without bias
+  const char* mask[4];
+  long long mask_nb;
+  float mask_slope;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -1056,24 +1078,33 @@ struct Env {
   lds_int_p ctl;       // LDS word: a dependency wait timed out
   int wave, tid;
   int n, tile, x0, y0;  // image, tile of the batch, first column / row of the tile
-  unsigned xvo[5];     // lane offsets of this wave's five tile pieces (per pair of chunks)
   unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
   unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
   unsigned plane_b;
-  int W;               // image width
+  int W, H;            // image width, height
   const char* xin;     // the image's concat buffer
   int xl[3];           // LDS byte offset of this lane's pixel operand at tap column dx (tile row of the wave)
   int wlane;           // LDS byte offset of this lane's weight operand inside a piece
   long long* dbg;
 };
 
+// Two chunks of a tile = 40 pieces of 1 KB, five per wave.  The lane offsets (pixel -> byte offset inside a channel-block plane, padding
+// -> out of range, bank swizzle as in conv_tile_h) are recomputed at every issue — ~60 vector instructions, six times per round —
+// rather than kept in five registers for the whole kernel.
 template <int AUX>
 __device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0) {
+  const int lane = e.tid & 63;
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int u = r * NW + e.wave;
     const int ci = u >= XU ? 1 : 0, pc = u - ci * XU;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, e.xvo[r],
+    const int q = pc * 64 + lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    const int gy = e.y0 - 1 + row, gx = e.x0 - 1 + col;
+    const bool valid = pix < XPIX && gy >= 0 && gy < e.H && gx >= 0 && gx < e.W;
+    const unsigned vo = valid ? (unsigned)((gy * e.W + gx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : 0xfffffff0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, vo,
                                              (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
   }
 }
@@ -1213,6 +1244,39 @@ __device__ __forceinline__ void epi_mid_lean(const Env& e, f32x16 (&acc)[PT], co
     }
 }
 
+struct MaskRegs {
+  u32x4v m[PT][2];  // [row][channel block]: the forward activation whose sign gates conv k's output, fetched one step ahead
+};
+__device__ __forceinline__ void fetch_mask(const Env& e, MaskRegs& M, const __amdgpu_buffer_rsrc_t m_rs) {
+  const unsigned vo = tile_lane_offset(e);
+#pragma unroll
+  for (int r = 0; r < PT; ++r)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      M.m[r][m] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, vo == 0xfffffff0u ? vo : vo + (unsigned)(r * e.W * 32), (unsigned)m * e.plane_b, 0);
+}
+template <int K>  // transposed block, conv K+1: dY = (mask > 0 ? 1 : mask_slope) * acc into blocks 4+2K, 5+2K of D, write-through
+__device__ __forceinline__ void epi_mid_mask(const Env& e, f32x16 (&acc)[PT], MaskRegs& M, const float mask_slope) {
+  const unsigned vo = tile_lane_offset(e);
+#pragma unroll
+  for (int r = 0; r < PT; ++r)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      u32x4v mm = M.m[r][m];
+      swap_halves4(mm);
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned w = mm[i >> 1];
+        const float t = acc[r][m * 8 + i];
+        v[i] = __builtin_bit_cast(float, (i & 1) ? (w & 0xffff0000u) : (w << 16)) > 0.f ? t : t * mask_slope;
+      }
+      u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      swap_halves4(o);
+      if (vo != 0xfffffff0u) store16((char*)e.xin + (size_t)(4 + 2 * K + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, true);
+    }
+}
+
 struct ResRegs {
   u32x4v r1[2][PT][2], r2[2][PT][2];  // [cout tile][row][channel block]: the residual sources of conv5's epilogue, fetched ahead
 };
@@ -1230,6 +1294,7 @@ __device__ __forceinline__ void fetch_residuals(const Env& e, ResRegs& R, const 
       }
 }
 // conv5: out = alpha (acc + bias) + beta1 res1 [+ beta2 res2]
+template <bool HAS_BIAS>
 __device__ __forceinline__ void epi_last_lean(const Env& e, f32x16 (&acc)[2][PT], ResRegs& R, char* out, const float alpha,
                                               const float beta1, const float beta2, const bool has_res2) {
   typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
@@ -1250,7 +1315,9 @@ __device__ __forceinline__ void epi_last_lean(const Env& e, f32x16 (&acc)[2][PT]
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float t = (acc[c][r][m * 8 + i] + bias[2 * m + (i >> 2)][i & 3]) * alpha;
+          float t = acc[c][r][m * 8 + i];
+          if constexpr (HAS_BIAS) t += bias[2 * m + (i >> 2)][i & 3];
+          t *= alpha;
           const unsigned wa = a[i >> 1], wb = b[i >> 1];
           t += beta1 * __builtin_bit_cast(float, (i & 1) ? (wa & 0xffff0000u) : (wa << 16));
           const float t2 = t + beta2 * __builtin_bit_cast(float, (i & 1) ? (wb & 0xffff0000u) : (wb << 16));
@@ -1282,8 +1349,8 @@ __device__ __forceinline__ void stamp(const Env& e, int i) {
   if (e.dbg && e.tid == 0) e.dbg[i] = __builtin_readcyclecounter();
 }
 
-template <int S, bool LEAN>
-__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+template <int S, int MODE>
+__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
                                         const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
   constexpr StepD d = kS.st[S];
   // the lane address bases pass through an empty asm at every step: derived addresses (tile buffer + column offset ...) are then
@@ -1294,7 +1361,7 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   if constexpr (d.tile_in > 0) {  // the neighbours' conv `tile_in` must be published before its tile is fetched
     stamp(e, 2 + 8 * (d.tile_in - 1) + 4);
     if (e.wave == 0) {
-      wait_vm<(LEAN ? kSL.st[S].Kflag : d.Kflag)>();  // the flag fetch of a few steps ago has landed
+      wait_vm<step_Kflag<MODE, S>()>();  // the flag fetch of a few steps ago has landed
       bool gave_up = false;
       const int lane = e.tid & 63;
       if (e.fvo != 0xfffffff0u) {
@@ -1317,7 +1384,7 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
       }
     }
   }
-  wait_vm<(LEAN ? kSL.st[S].K : d.K)>();
+  wait_vm<step_K<MODE, S>()>();
   __builtin_amdgcn_s_barrier();
   if constexpr (S == 0) stamp(e, 1);
   if constexpr (d.tile_in > 0) stamp(e, 2 + 8 * (d.tile_in - 1) + 5);
@@ -1336,13 +1403,23 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   if constexpr (d.flag_in > 0) {
     if (e.wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
   }
-  if constexpr (LEAN && d.first_of_in == 4) {  // conv5's residual sources: 16 loads per wave that land under the last input's MFMAs
+  if constexpr (MODE != 0 && d.first_of_in == 4) {  // conv5's residual sources: 16 loads per wave that land under the last input's MFMAs
     const char* r1 = kernarg_at<const char*>(offsetof(FusedParams, res1));
     const char* r2 = kernarg_at<const char*>(offsetof(FusedParams, res2));
     const long long nb1 = kernarg_at<long long>(offsetof(FusedParams, res1_nb)), nb2 = kernarg_at<long long>(offsetof(FusedParams, res2_nb));
     __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
     fetch_residuals(e, R, make_rsrc(r1 + e.n * nb1, 4u * e.plane_b), make_rsrc(r2 ? r2 + e.n * nb2 : r1, r2 ? 4u * e.plane_b : 0u));
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (MODE == 2) {  // the mask of the conv that completes with this step or the next
+    constexpr int k = mask_conv_at(kS, S);
+    if constexpr (k >= 1) {
+      const char* mp = kernarg_at<const char*>(offsetof(FusedParams, mask) + (k - 1) * sizeof(const char*));
+      const long long nbm = kernarg_at<long long>(offsetof(FusedParams, mask_nb));
+      __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
+      fetch_mask(e, M, make_rsrc(mp + e.n * nbm, 2u * e.plane_b));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   if constexpr (d.post > 0 && d.post < 5) stamp(e, 2 + 8 * (d.post - 1));  // last step of conv `post` runs
   if constexpr (d.post == 5) stamp(e, 40);
@@ -1356,14 +1433,17 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
     }
   compute_step<S>(e, acc, o);
   typedef const __attribute__((address_space(3))) float* lds_float_p;
-  if constexpr (LEAN && d.post > 0 && d.post < 5) {
+  if constexpr (MODE == 1 && d.post > 0 && d.post < 5) {
     epi_mid_lean<d.post - 1>(e, acc[d.post - 1], x_rs, kernarg_at<float>(offsetof(FusedParams, slope)));
     stamp(e, 2 + 8 * (d.post - 1) + 1);
-  } else if constexpr (LEAN && d.post == 5) {
+  } else if constexpr (MODE == 2 && d.post > 0 && d.post < 5) {
+    epi_mid_mask<d.post - 1>(e, acc[d.post - 1], M, kernarg_at<float>(offsetof(FusedParams, mask_slope)));
+    stamp(e, 2 + 8 * (d.post - 1) + 1);
+  } else if constexpr (MODE != 0 && d.post == 5) {
     stamp(e, 41);
     char* o5 = kernarg_at<char*>(offsetof(FusedParams, out5));
     const long long nbo = kernarg_at<long long>(offsetof(FusedParams, out5_nb));
-    epi_last_lean(e, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), R, o5 + e.n * nbo,
+    epi_last_lean<MODE == 1>(e, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), R, o5 + e.n * nbo,
                   kernarg_at<float>(offsetof(FusedParams, alpha5)), kernarg_at<float>(offsetof(FusedParams, beta1)),
                   kernarg_at<float>(offsetof(FusedParams, beta2)), kernarg_at<const char*>(offsetof(FusedParams, res2)) != nullptr);
   } else if constexpr (d.post > 0 && d.post < 5) {
@@ -1382,12 +1462,12 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   return true;
 }
 
-template <int S, bool LEAN>
-__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
+template <int S, int MODE>
+__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
                                           const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
   if constexpr (S < kS.nsteps) {
-    if (!do_step<S, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs)) return false;
-    return run_steps<S + 1, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs);
+    if (!do_step<S, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs)) return false;
+    return run_steps<S + 1, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs);
   } else {
     return true;
   }
@@ -1395,7 +1475,7 @@ __device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o,
 
 }  // namespace fz
 
-template <bool LEAN>
+template <int MODE>  // epilogues: 0 generic (epilogue_cb16), 1 lean forward block, 2 lean transposed block
 __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedParams P) {
   using namespace fz;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1411,6 +1491,7 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   const ConvParamsH& p0 = P.lv[0];
   e.plane_b = (unsigned)(p0.H * p0.W * 32);
   e.W = p0.W;
+  e.H = p0.H;
   e.wvo = (lane ^ ((lane >> 4) & 1)) * 16;
   e.wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);
   const int xrow0 = ((e.wave * PT) * XROW + j) * 32;
@@ -1436,18 +1517,6 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   const int x0 = tx * 32, y0 = ty * TH;
   e.x0 = x0;
   e.y0 = y0;
-  // lane offsets of this wave's tile pieces (they do not depend on the image)
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int u = r * NW + e.wave;
-    const int pc = u >= XU ? u - XU : u;
-    const int q = pc * 64 + lane;
-    const int pix = q >> 1, half = q & 1;
-    const int row = pix / XROW, col = pix - row * XROW;
-    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-    const bool valid = pix < XPIX && gy >= 0 && gy < p0.H && gx >= 0 && gx < p0.W;
-    e.xvo[r] = valid ? (unsigned)((gy * p0.W + gx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : 0xfffffff0u;
-  }
   // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
   int nb = -1;
   if (e.wave == 0 && lane < 9) {
@@ -1477,7 +1546,8 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     f32x16 acc[NG][PT];
     Ops o;
     ResRegs R;
-    if (!run_steps<0, LEAN>(e, acc, o, R, P, x_rs, w_rs, f_rs, nx_rs)) break;
+    MaskRegs M;
+    if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs)) break;
     stamp(e, 42);
   }
   fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
@@ -1621,10 +1691,11 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   static int cu_count[16] = {0};
   if (dev < 0 || dev >= 16) return SR_OK;
   if (cu_count[dev] == 0) {
-    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<false>, fz::LDS_BYTES)) return rc;
-    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<true>, fz::LDS_BYTES)) return rc;
+    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<0>, fz::LDS_BYTES)) return rc;
+    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<1>, fz::LDS_BYTES)) return rc;
+    if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused_bf16_kernel<2>, fz::LDS_BYTES)) return rc;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rdb_fused_bf16_kernel<true>, 512, fz::LDS_BYTES) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rdb_fused_bf16_kernel<1>, 512, fz::LDS_BYTES) != hipSuccess ||
         per_cu < 1) {
       cu_count[dev] = -1;
     } else {
@@ -1665,12 +1736,19 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.epoch = call_index * 8;
   P.dbg = g_fused_clocks;
   // the forward block's epilogues in their lean form: conv1-4 = LeakyReLU(conv + bias), conv5 = alpha (conv + bias) + beta1 res1 [+ beta2 res2]
-  bool lean = d[4].bpacked && d[4].act_slope == 1.f && d[4].res1 && !d[4].mask_src && d[4].res1_img_stride >= 64 * hw &&
-              (!d[4].res2 || d[4].res2_img_stride >= 64 * hw) && d[4].out_img_stride >= 64 * hw;
+  bool lean = d[4].bpacked != nullptr;
   for (int k = 0; k < 4 && lean; ++k)
     lean = d[k].bpacked && d[k].alpha == 1.f && !d[k].mask_src && d[k].act_slope == d[0].act_slope && d[k].act_slope >= 0.f && d[k].act_slope <= 1.f;
-  if (g_chain_enabled == 4) lean = false;  // development: the generic epilogues
-  if (lean) {
+  // ... and the transposed block's: conv1-4 = lrelu'(mask) * conv, conv5 = conv + beta1 res1 [+ beta2 res2]
+  const bool tail_ok = d[4].res1 && !d[4].mask_src && d[4].res1_img_stride >= 64 * hw && (!d[4].res2 || d[4].res2_img_stride >= 64 * hw) &&
+                       d[4].out_img_stride >= 64 * hw && d[4].act_slope == 1.f;
+  bool back = tail_ok && !d[4].bpacked && d[4].alpha == 1.f;
+  for (int k = 0; k < 4 && back; ++k)
+    back = !d[k].bpacked && d[k].alpha == 1.f && d[k].act_slope == 1.f && d[k].mask_src && d[k].mask_cbn >= 2 &&
+           d[k].mask_img_stride == d[0].mask_img_stride && d[k].mask_img_stride >= 32 * hw && d[k].mask_slope == d[0].mask_slope;
+  lean = lean && tail_ok;
+  if (g_chain_enabled == 4) lean = back = false;  // development: the generic epilogues
+  if (lean || back) {
     P.slope = d[0].act_slope;
     P.alpha5 = d[4].alpha;
     P.beta1 = d[4].beta1;
@@ -1681,10 +1759,16 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     P.res1_nb = P.lv[4].res1_nb;
     P.res2 = P.lv[4].res2;
     P.res2_nb = P.lv[4].res2_nb;
-    hipLaunchKernelGGL(rdb_fused_bf16_kernel<true>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
-  } else {
-    hipLaunchKernelGGL(rdb_fused_bf16_kernel<false>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+    for (int k = 0; k < 4; ++k) P.mask[k] = P.lv[k].mask;
+    P.mask_nb = P.lv[0].mask_nb;
+    P.mask_slope = d[0].mask_slope;
   }
+  if (lean)
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  else if (back)
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<2>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  else
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<0>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
   SR_CHECK_LAUNCH("rdb_fused_bf16 launch");
   *launched = true;
   return SR_OK;

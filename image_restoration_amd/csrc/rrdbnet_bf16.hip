@@ -111,6 +111,8 @@ FwdSpaceH carve_fwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
 struct BwdSpaceH {
   __bf16 *dyl, *a16, *b16, *a4, *b4, *dtrunk, *g[4], *dxin;
   void* slab;
+  int32_t* sync;  // hand-off words of the transposed dense blocks' chain launches
+  size_t sync_ints;
   size_t slab_bytes, bytes;
 };
 BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, int w, char* base) {
@@ -130,6 +132,8 @@ BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
   const size_t rdb_bytes = sr_rdb_wgrad_slab_bytes_bf16(n, h, w, c->num_feat, c->num_grow_ch);
   if (rdb_bytes > B.slab_bytes) B.slab_bytes = rdb_bytes;
   B.slab = cv.take(B.slab_bytes / 2);
+  B.sync_ints = sr_conv3x3_chain_sync_ints(n, h, w);
+  B.sync = (int32_t*)cv.take(B.sync_ints * 2);  // take() counts 2-byte elements
   B.bytes = cv.off;
   return B;
 }
@@ -509,7 +513,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   if (rc) return rc;
   // body, in reverse: each RDB's data gradient is a transposed dense block over D = [dY5 | dY4 | dY3 | dY2 | dY1]
   auto step = [&](int q, int sidx, const __bf16* in, int cin_pad, __bf16* out, int cout, const __bf16* r1, float b1,
-                  const __bf16* r2, float b2, const __bf16* mask, int mask_cbn) -> int {
+                  const __bf16* r2, float b2, const __bf16* mask, int mask_cbn) {
     sr_conv3x3_desc d = {};
     d.in = (const float*)in;
     d.in_img_stride = cat_ns;
@@ -534,8 +538,13 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     d.mask_img_stride = cat_ns;
     d.mask_cbn = mask_cbn;
     d.mask_slope = 0.2f;
-    return sr_conv3x3_bf16(&d, stream);
+    return d;
   };
+  if (hipMemsetAsync(B.sync, 0, B.sync_ints * sizeof(int32_t), stream) != hipSuccess) {
+    sr::set_error("sr_rrdbnet_backward_bf16: sync memset failed");
+    return SR_ELAUNCH;
+  }
+  int chain_call = 0;
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const __bf16* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
@@ -544,18 +553,19 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       __bf16* D = B.g[gi];  // D[0:nf] = dL/d(block output)
       __bf16* Dn = B.g[(gi + 1) & 3];
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
-      for (int sl = 4; sl >= 1; --sl) {  // dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k
-        __bf16* dys = D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw;
-        rc = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, dys, cfg->num_grow_ch, nullptr, 0.f, nullptr, 0.f,
-                  cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
-        if (rc) return rc;
-      }
-      // all five weight gradients of the block in one launch (conv5: dY5 = s5 * D[0:nf]); D stays intact meanwhile
+      // The transposed dense block as one chain of five convs over D (sr_conv3x3_chain_bf16: one launch where the shape allows):
+      //   dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k   for sl = 4..1, each appended to D, then
+      //   dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63) into the next D.
+      sr_conv3x3_desc dd[5];
+      for (int sl = 4; sl >= 1; --sl)
+        dd[4 - sl] = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw, cfg->num_grow_ch, nullptr, 0.f,
+                          nullptr, 0.f, cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
+      dd[4] = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
+      rc = sr_conv3x3_chain_bf16(dd, 5, B.sync, chain_call++, stream);
+      if (rc) return rc;
+      // all five weight gradients of the block in one launch (conv5: dY5 = s5 * D[0:nf]); D is complete and stays intact
       rc = sr::rdb_wgrad_bf16(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5,
                               accumulate, B.slab, B.slab_bytes, stream);
-      if (rc) return rc;
-      // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
-      rc = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
       if (rc) return rc;
       gi = (gi + 1) & 3;
     }

@@ -130,3 +130,45 @@ def test_chain_can_be_switched_off(cuda):
     H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc))
     torch.cuda.synchronize()
     assert torch.equal(cat_a.buf, cat_b.buf) and torch.equal(nxt_a.buf[:, :4], nxt_b.buf[:, :4])
+
+
+@pytest.mark.parametrize('n,h,w', [(16, 128, 128), (20, 128, 128), (5, 208, 96), (2, 64, 40)])
+@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('closing', [False, True])
+def test_transposed_block_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, mode, closing):
+    """The data-gradient side of a dense block (sr_rrdbnet_backward_bf16): the same chain shape over D = [dY5 | dY4 .. dY1], no bias, the
+    LeakyReLU-backward mask of the forward activation on conv1-4, the residual sum(s) on conv5 — in mode 3 the fused kernel's lean
+    transposed-block epilogues (masks and residual sources fetched ahead of the epilogues)."""
+    _lib.check(_lib.load().sr_set_conv_chain(mode), 'sr_set_conv_chain')
+    nf, gc = 64, 32
+    g = torch.Generator().manual_seed(7)
+    packs = []
+    for k in range(1, 6):
+        cout, cin = (nf if k == 5 else gc), nf + (k - 1) * gc
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) * (0.6 / (cin * 9) ** 0.5)).to(cuda)
+        packs.append(H.PackedConvBF16(wt, None, first_seg=nf, seg=gc))
+    fwd = H.CB16(torch.randn(n, (nf + 4 * gc) // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda))   # saved activations
+    rrdb = H.CB16(torch.randn(n, nf // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda))
+
+    def steps(cat, nxt):
+        st = []
+        for k in range(1, 5):
+            st.append((cat.slice(0, nf + (k - 1) * gc), packs[k - 1], cat.slice(nf + (k - 1) * gc, gc),
+                       dict(mask=fwd.slice(nf + (4 - k) * gc, gc), mask_slope=0.2)))
+        kw = dict(res1=cat.slice(0, nf), beta1=0.2 if closing else 1.0)
+        if closing:
+            kw.update(res2=rrdb, beta2=1.0)
+        st.append((cat, packs[4], nxt.slice(0, nf), kw))
+        return st
+
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
+    for src, pc, out, kw in steps(cat_a, nxt_a):
+        H.conv3x3_bf16(src, pc, out, **kw)
+    sync = None
+    for rep in range(2):
+        cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+        _, sync = H.conv3x3_chain_bf16(steps(cat_b, nxt_b), sync, call_index=rep)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        assert torch.equal(cat_a.buf, cat_b.buf), rep
+        assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
