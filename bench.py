@@ -293,6 +293,31 @@ def secondary_workloads(net, args, world, rank, dev, dist, backend):
             out[name] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
             torch.cuda.empty_cache()
 
+    def infer_bf16():
+        from image_restoration_amd.utils import synth
+        net.set_compute_dtype('bf16')
+        x = torch.from_numpy(synth.uniform_input(1234 + rank, (BATCH, 3, TILE, TILE))).to(dev)
+        steps = 20
+        with torch.no_grad():
+            for _ in range(3):
+                y = net(x)
+            _sync(dist)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = net(x)
+            _sync(dist)
+            dt = _max_over_ranks(time.perf_counter() - t0, dist, dev, backend)
+        assert bool(torch.isfinite(y).all())
+        res = {'metric': 'images/sec (128x128->512x512 x4 SR, 23-block RRDBNet)', 'value': round(world * BATCH * steps / dt, 3),
+               'unit': 'images/sec', 'steps': steps, 'ms_per_step': round(dt / steps * 1e3, 3), 'dtype': 'bf16', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[1] in bf16 (fp32 weights rounded once, fp32 accumulation): batch 16 of 128x128 tiles per GPU'}}
+        if world == 1:
+            ks = kernel_rooflines(net, x, PEAK_BF16_TFLOPS)
+            res['roofline'] = roofline_of(ks, PEAK_BF16_TFLOPS)
+            res['kernels'] = ks[:4]
+        return res
+
+    guarded('c2_infer_bf16', infer_bf16)
     guarded('c5_tiled_4k_bf16', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='bf16', steps=2, warmup=1,
                                                       tile_batch=args.tile_batch, profile=True))
     guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=1, warmup=0,

@@ -1763,12 +1763,28 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     P.mask_nb = P.lv[0].mask_nb;
     P.mask_slope = d[0].mask_slope;
   }
+  const bool prof = sr::prof_on();
+  if (prof) {  // one record for the whole block: the FLOPs of its five convs, the bytes a block must move at least
+    sr_launch_record r = {};
+    r.kernel_id = 60 + (lean ? 1 : back ? 2 : 0);
+    r.cin = 192;
+    r.cout = 192;
+    r.n = n;
+    r.h = h;
+    r.w = w;
+    const double px = (double)n * hw;
+    r.flops = 2.0 * 9 * px * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);
+    // x read, x1..x4 written, the output written, the residual sources (and the four masks of the transposed block) read
+    r.bytes = 2.0 * px * (64 + 128 + 64 + (d[4].res1 ? 64 : 0) + (d[4].res2 ? 64 : 0) + (d[0].mask_src ? 128 : 0));
+    sr::prof_begin(stream, r);
+  }
   if (lean)
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
   else if (back)
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<2>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
   else
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<0>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+  if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("rdb_fused_bf16 launch");
   *launched = true;
   return SR_OK;
@@ -1777,7 +1793,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
-  if (g_chain_enabled >= 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS && !sr::prof_on()) {
+  if (g_chain_enabled >= 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS) {  // (also when profiling: one record)
     bool launched = false;
     if (int rc = try_fused_dense_block(d, sync, call_index, stream, &launched)) return rc;
     if (launched) return SR_OK;

@@ -48,3 +48,4 @@ def run(n, h, w, nf=64, gc=32):
 
 if __name__ == '__main__':
     run(8, 128, 128)
+    run(16, 128, 128)

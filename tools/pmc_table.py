@@ -33,7 +33,7 @@ def main():
             for n, vals in cs.items():
                 allk[k][n] = (sum(vals) / len(vals), len(vals))
     for k in sorted(allk, key=lambda k: -allk[k].get('SQ_BUSY_CYCLES', allk[k].get('GRBM_GUI_ACTIVE', (0, 0)))[0] * allk[k].get('SQ_BUSY_CYCLES', allk[k].get('GRBM_GUI_ACTIVE', (0, 1)))[1]):
-        if not any(t in k for t in ('conv', 'wgrad')):
+        if not any(t in k for t in ('conv', 'wgrad', 'rdb_')):
             continue
         print(k[:120])
         for n in sorted(allk[k]):
