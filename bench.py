@@ -350,6 +350,7 @@ def main():
     ap.add_argument('--chain', type=int, default=0, help='tuning: dense blocks as one persistent chain launch each (sr_set_conv_chain*): 1 = 32-row tiles, 2 = 16-row tiles (bf16)')
     ap.add_argument('--rows8', type=int, default=-1, help='tuning: fp32 32-cout convs on 16- (0), 8- (1) or 4-row (2) tiles (development switch)')
     ap.add_argument('--tall64', action='store_true', help='tuning: fp32 64-cout convs on 16-row tiles (development switch)')
+    ap.add_argument('--stream', type=int, default=-1, help='tuning: 0 = large few-channel bf16 convs on the per-tile kernel instead of the streaming kernel (development switch)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C3 training step and the C5 tiled frame next to the headline')
     ap.add_argument('--secondary-timeout', type=float, default=300.0)
     ap.add_argument('--profile', action='store_true', help='--mode train|tiled: add the roofline of the dominant kernel')
@@ -382,6 +383,9 @@ def main():
     if args.tall64:
         from image_restoration_amd import _lib
         _lib.load().sr_dev_set_f32_tall64(1)
+    if args.stream >= 0:
+        from image_restoration_amd import _lib
+        _lib.load().sr_dev_set_conv_stream(args.stream)
     if args.chain:
         from image_restoration_amd import _lib
         _lib.check(_lib.load().sr_set_conv_chain(args.chain), 'sr_set_conv_chain')

@@ -1553,6 +1553,322 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
 }
 
+// ------------------------------------------------------------------------------------------------ streaming conv (Cin <= 64)
+// The large-image layers with few input channels — conv_hr / the upsampling convs of the generator's head, the U-Net
+// discriminator's 512x512 and 256x256 levels and their data gradients — are 1-4 chunks deep: on the per-tile kernel above a tile is
+// a prologue (first chunk's latency), 1-4 short chunk steps and an epilogue, and every tile re-fetches the whole weight image
+// (half of its L2 -> LDS traffic); measured 0.39 of HBM and 0.37 of the MFMA peak on 64 -> 64 channels at 512x512.  Here one
+// workgroup per CU walks a strip of tiles with ONE continuous pipeline: the weights (<= 72 KB) stay in the LDS for the whole launch,
+// tile chunks stream through a ring of NS = 4-6 buffers that runs across tile boundaries (D = NS-1 chunks in flight: the next
+// tiles' data is on its way while this tile is multiplied and stored), every step is a counted s_waitcnt vmcnt + raw s_barrier, and
+// the one optional extra operand of the epilogue (a residual source or the LeakyReLU-backward mask) is fetched one tile ahead,
+// in issue order behind that tile's chunks, so it never waits behind the ring's younger LDS-DMA.
+namespace st {
+constexpr int NW = 8, PT = 2, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW, XU = 20, XBUF = XU * 1024;
+constexpr int R = 3;  // LDS-DMA pieces per wave and chunk (24 >= 20: the extra ones copy nothing into a spare piece)
+
+template <int COT, int NC, bool AUX>
+struct Cfg {
+  static constexpr int WBYTES = NC * 9 * COT * 1024;
+  static constexpr int NS_FIT = (160 * 1024 - WBYTES - 1024 - 512) / XBUF;
+  static constexpr int NS_MAX = NC == 1 ? 4 : 6;  // (one-chunk tiles: every ring slot is a tile with its own loads and stores in flight)
+  static constexpr int NS = NS_FIT > NS_MAX ? NS_MAX : NS_FIT;
+  static constexpr int D = NS - 1;
+  static constexpr int LDS_RING = WBYTES, LDS_SPARE = WBYTES + NS * XBUF, LDS_BIAS = LDS_SPARE + 1024, LDS_BYTES = LDS_BIAS + 256;
+  static constexpr int A = AUX ? 4 * COT : 0;  // loads of the extra epilogue operand per tile
+  static constexpr int S = 4 * COT;            // stores per tile
+  static_assert(NS >= 3 && D <= 5, "ring length");
+  // what may stay in flight when step (tile t, chunk c) starts: the operations issued after that chunk's LDS-DMA.  The issue
+  // sequence of a wave: prologue = chunks 0..D-1 (the extra operand of tile 0 right behind chunk 0); step g = chunk g+D, then, on a
+  // tile's first chunk, the previous tile's stores and the next tile's extra operand.
+  static constexpr int K(int t, int c) {
+    int seq = 0, pos[64] = {};
+    for (int g = 0; g < D; ++g) {
+      seq += R;
+      pos[g] = seq;
+      if (g == 0) seq += A;
+    }
+    int k = 0;
+    for (int g = 0; g <= t * NC + c; ++g) {
+      k = seq - pos[g];
+      seq += R;
+      pos[g + D] = seq;
+      if (g % NC == 0) seq += (g > 0 ? S : 0) + A;
+    }
+    return k > 63 ? 63 : k;  // the counter's range (waiting for more than necessary is safe)
+  }
+};
+
+struct Cursor {  // a position in the workgroup's strip of tiles
+  int ti, n, ty, tx;
+  __device__ __forceinline__ void next(const ConvParamsH& p) {
+    ++ti;
+    if (++tx == p.tiles_x) {
+      tx = 0;
+      if (++ty == p.tiles_y) {
+        ty = 0;
+        ++n;
+      }
+    }
+  }
+};
+
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+}  // namespace st
+
+template <int COT, int NC, bool AUX>
+__global__ __launch_bounds__(512, 2) void conv_stream_bf16_kernel(const ConvParamsH p, const int per, const int aux_kind) {
+  using namespace st;
+  typedef Cfg<COT, NC, AUX> C;
+  typedef __attribute__((address_space(3))) void* lds_void_p;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int NT = p.tiles_x * p.tiles_y * p.cogs;  // cogs carries the image count here
+  const int t0 = blockIdx.x * per, t1 = t0 + per < NT ? t0 + per : NT;
+  if (t0 >= t1) return;
+  const unsigned plane_b = (unsigned)(p.in_h * p.in_w * 32), oplane_b = (unsigned)(p.H * p.W * 32);
+  // the weight image and the bias become resident
+  {
+    const __amdgpu_buffer_rsrc_t w_rs = rsrc(p.w, (unsigned)C::WBYTES);
+    const unsigned wvo = (lane ^ ((lane >> 4) & 1)) * 16;
+    for (int u = wave; u < NC * 9 * COT; u += NW)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_p)(smem + u * 1024), 16, wvo, (unsigned)u * 1024u, 0, 0);
+    if (tid < 64) ((float*)(smem + C::LDS_BIAS))[tid] = (p.bias && tid < 32 * COT) ? p.bias[tid] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t null_rs = rsrc(p.in, 0u);
+  // issue side: the cursor runs D chunks ahead of the compute side
+  Cursor ic = {t0, 0, 0, 0};
+  {
+    int t = t0;
+    ic.tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    ic.ty = t % p.tiles_y;
+    ic.n = t / p.tiles_y;
+  }
+  Cursor cc = ic;
+  int ichunk = 0, islot = 0;
+  unsigned xvo[R];
+  auto lane_offsets = [&](const Cursor& c) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int u = r * NW + wave;
+      const int q = u * 64 + lane;
+      const int pix = q >> 1, half = q & 1;
+      const int row = pix / XROW, col = pix - row * XROW;
+      const int gy = c.ty * TH - 1 + row, gx = c.tx * 32 - 1 + col;
+      const bool valid = u < XU && pix < XPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      xvo[r] = valid ? (unsigned)((((gy >> p.src_shift) * p.in_w + (gx >> p.src_shift)) * 32 + (half ^ ((col >> 3) & 1)) * 16)) : 0xfffffff0u;
+    }
+  };
+  auto issue_chunk = [&]() {  // the chunk under the issue cursor (nothing real behind the strip's end: same instruction count)
+    const bool live = ic.ti < t1;
+    if (ichunk == 0) lane_offsets(ic);
+    const __amdgpu_buffer_rsrc_t x_rs = live ? rsrc(p.in + (long long)ic.n * p.in_nb, (unsigned)NC * plane_b) : null_rs;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int u = r * NW + wave;
+      char* dst = u < XU ? smem + C::LDS_RING + islot * XBUF + u * 1024 : smem + C::LDS_SPARE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)dst, 16, xvo[r], (unsigned)ichunk * plane_b, 0, 0);
+    }
+    islot = islot + 1 == C::NS ? 0 : islot + 1;
+    if (++ichunk == NC) {
+      ichunk = 0;
+      ic.next(p);
+    }
+  };
+  // the extra epilogue operand of a tile (residual source or mask): 4 * COT loads, double-buffered over tiles
+  u32x4s aux[COT][PT][2], aux_next[COT][PT][2];  // this tile's / the next tile's (registers: no run-time indexing)
+  auto out_lane_offset = [&](const Cursor& c) {
+    const int x = c.tx * 32 + j;
+    return x < p.W ? (unsigned)(((c.ty * TH + wave * PT) * p.W + x) * 32 + h * 16) : 0xfffffff0u;
+  };
+  auto fetch_aux = [&](const Cursor& c, u32x4s (&dst)[COT][PT][2]) {
+    if constexpr (AUX) {
+      const char* base = aux_kind == 0 ? p.res1 : aux_kind == 1 ? p.res2 : p.mask;
+      const long long nb = aux_kind == 0 ? p.res1_nb : aux_kind == 1 ? p.res2_nb : p.mask_nb;
+      const bool live = c.ti < t1;
+      const __amdgpu_buffer_rsrc_t a_rs = live ? rsrc(base + (long long)c.n * nb, (unsigned)(2 * COT) * oplane_b) : null_rs;
+      const unsigned vo = out_lane_offset(c);
+#pragma unroll
+      for (int cg = 0; cg < COT; ++cg)
+#pragma unroll
+        for (int r = 0; r < PT; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            dst[cg][r][m] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, vo == 0xfffffff0u ? vo : vo + (unsigned)(r * p.W * 32),
+                                                                      (unsigned)(cg * 2 + m) * oplane_b, 0);
+    }
+  };
+
+  // prologue
+#pragma unroll
+  for (int g = 0; g < C::D; ++g) {
+    issue_chunk();
+    if (g == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_aux(cc, aux_next);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  const int xrow0 = ((wave * PT) * XROW + j) * 32;
+  int xl[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) xl[dx] = xrow0 + dx * 32 + ((h ^ (((j + dx) >> 3) & 1)) * 16);
+  const int wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);
+  int cslot = 0;
+
+  // One third of a tile's epilogue (store groups [3 part, 3 part + 3) of 4 COT): the operations and their order are epilogue_cb16's
+  // (bias, LeakyReLU, scale, residual scale-add, mask); the extra operand comes out of the registers it was fetched into.
+  auto epilogue_part = [&](f32x16 (&ac)[COT][PT], const Cursor& c, const int part) {
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
+    const unsigned vo = out_lane_offset(c);
+    const bool has_bias = p.bias != nullptr;
+    const float beta = aux_kind == 0 ? p.beta1 : p.beta2;
+#pragma unroll
+    for (int grp = 3 * part; grp < 3 * part + 3 && grp < 4 * COT; ++grp) {
+      const int cg = grp >> 2, r = (grp >> 1) & 1, m = grp & 1;
+      u32x4s ax = {0u, 0u, 0u, 0u};
+      if constexpr (AUX) {
+        ax = aux[cg][r][m];
+        auto r0 = __builtin_amdgcn_permlane32_swap(ax[0], ax[2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(ax[1], ax[3], false, false);
+        ax = u32x4s{r0[0], r1[0], r0[1], r1[1]};
+      }
+      f32x4 bias[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) bias[q] = *(lds_f4_p)(smem + C::LDS_BIAS + (cg * 32 + (2 * m + q) * 8 + h * 4) * 4);
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float tt = ac[cg][r][m * 8 + i];
+        if (has_bias) tt += bias[i >> 2][i & 3];
+        tt = tt > 0.f ? tt : tt * p.slope;
+        tt *= p.alpha;
+        if constexpr (AUX) {
+          const unsigned wa = ax[i >> 1];
+          const float av = __builtin_bit_cast(float, (i & 1) ? (wa & 0xffff0000u) : (wa << 16));
+          if (aux_kind < 2)
+            tt += beta * av;
+          else if (!(av > 0.f))
+            tt *= p.mask_slope;
+        }
+        v[i] = tt;
+      }
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      auto pk = [](float lo, float hi) {
+        bf16x2 q = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(unsigned, q);
+      };
+      u32x4s o = {pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
+      auto s0 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+      o = u32x4s{s0[0], s1[0], s0[1], s1[1]};
+      // exec-masked where the column lies beyond the image: the instruction is issued either way (the waits count it)
+      if (vo != 0xfffffff0u)
+        store16(p.out + (long long)c.n * p.out_nb + (size_t)(cg * 2 + m) * oplane_b + vo + (unsigned)(r * p.W * 32), o, false);
+    }
+  };
+
+  // A tile: NC chunk steps.  The epilogue of the PREVIOUS tile rides on this tile's first chunk — a third of it behind the MFMAs of
+  // each tap column, vector work in the matrix pipe's shadow — instead of holding every wave of the workgroup between two tiles.
+  Cursor pc = cc;
+  bool have_prev = false;
+  auto tile_body = [&](f32x16 (&acc)[COT][PT], f32x16 (&accp)[COT][PT], const int trel) {
+#pragma unroll
+    for (int a = 0; a < COT; ++a)
+#pragma unroll
+      for (int b = 0; b < PT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      // steady from the tile whose chunks were all issued by regular steps (t * NC + c >= D): seven tile cases cover D <= 5
+#define SR_ST_WAIT(T)                                                                                          \
+  switch (c) {                                                                                                 \
+    case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::K(T, 0)) : "memory"); break;                           \
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::K(T, NC > 1 ? 1 : 0)) : "memory"); break;             \
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::K(T, NC > 2 ? 2 : 0)) : "memory"); break;             \
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::K(T, NC > 3 ? 3 : 0)) : "memory"); break;            \
+  }
+      switch (trel < 6 ? trel : 6) {
+        case 0: SR_ST_WAIT(0) break;
+        case 1: SR_ST_WAIT(1) break;
+        case 2: SR_ST_WAIT(2) break;
+        case 3: SR_ST_WAIT(3) break;
+        case 4: SR_ST_WAIT(4) break;
+        case 5: SR_ST_WAIT(5) break;
+        default: SR_ST_WAIT(6) break;
+      }
+#undef SR_ST_WAIT
+      __builtin_amdgcn_s_barrier();
+      issue_chunk();
+      const char* xb = smem + C::LDS_RING + cslot * XBUF;
+      const char* ws = smem + c * (9 * COT * 1024) + wlane;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        bf16x8 bx[PT + 2], a[3][COT];
+        const char* xs = xb + xl[dx];
+#pragma unroll
+        for (int r = 0; r < PT + 2; ++r) bx[r] = *(const bf16x8*)(xs + r * XROW * 32);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int cg = 0; cg < COT; ++cg) a[dy][cg] = *(const bf16x8*)(ws + ((dy * 3 + dx) * COT + cg) * 1024);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int cg = 0; cg < COT; ++cg)
+#pragma unroll
+            for (int r = 0; r < PT; ++r)
+              acc[cg][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][cg], bx[r + dy], acc[cg][r], 0, 0, 0);
+        if (c == 0 && have_prev) epilogue_part(accp, pc, dx);
+      }
+      if (c == 0) {  // this tile's extra operand moves up, the next tile's is fetched (behind the stores above in the issue order)
+        if constexpr (AUX) {
+#pragma unroll
+          for (int cg = 0; cg < COT; ++cg)
+#pragma unroll
+            for (int r = 0; r < PT; ++r)
+#pragma unroll
+              for (int m = 0; m < 2; ++m) aux[cg][r][m] = aux_next[cg][r][m];
+        }
+        Cursor nx = cc;
+        nx.next(p);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_aux(nx, aux_next);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cslot = cslot + 1 == C::NS ? 0 : cslot + 1;
+    }
+    pc = cc;
+    have_prev = true;
+    cc.next(p);
+  };
+  f32x16 acc0[COT][PT], acc1[COT][PT];
+  int t = t0;
+  for (; t + 1 < t1; t += 2) {
+    tile_body(acc0, acc1, t - t0);
+    tile_body(acc1, acc0, t + 1 - t0);
+  }
+  if (t < t1) {
+    tile_body(acc0, acc1, t - t0);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) epilogue_part(acc0, pc, part);
+  } else {
+#pragma unroll
+    for (int part = 0; part < 3; ++part) epilogue_part(acc1, pc, part);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's read-ahead behind the strip lands before the LDS is released
+}
+
 template <int COT, int PT, int NW>
 constexpr int conv_bf16_lds() {
   return 2 * ((((NW * PT + 2) * 34 * 32 + 1023) / 1024) * 1024 + 9 * COT * 1024);
@@ -1858,6 +2174,10 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
 
 // d->in / out / res*: CB16 bf16 tensors (out: NCHW fp32 when out_nchw); *_img_stride in ELEMENTS of the tensor's dtype;
 // cin_pad multiple of 16; wpacked from sr_conv3x3_pack_bf16 (passed through the float* field); bpacked fp32.
+static int g_stream_enabled = 1;
+// Development switch (not part of the ABI): 0 = large few-channel convs on the per-tile kernel instead of conv_stream_bf16_kernel.
+extern "C" void sr_dev_set_conv_stream(int on) { g_stream_enabled = on; }
+
 extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvParamsH p;
@@ -1896,6 +2216,57 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
     }
     if (gc == 64) return w8 ? launch_h<2, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<2, 2, 4, true>(p, d->n, groups, stream, d);
     return w8 ? launch_h<1, 4, 8, true>(p, d->n, groups, stream, d) : launch_h<1, 2, 4, true>(p, d->n, groups, stream, d);
+  }
+  // Few input channels on a large pixel grid: the streaming kernel (resident weights, one pipeline across a strip of tiles)
+  if (g_stream_enabled && p.cin_blocks <= 4 && d->cout == 64 && d->s2_channels == 0 && p.H % 16 == 0) {
+    const int naux = (d->res1 ? 1 : 0) + (d->res2 ? 1 : 0) + (d->mask_src ? 1 : 0);
+    int dev = 0, cus = 0;
+    if (naux <= 1 && !(naux == 1 && p.cin_blocks == 2) /* that instance spills */ && (!d->mask_src || d->mask_cbn >= 4) && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+      const int conc0 = sr::launch_concurrency();
+      const int grid = cus / (conc0 > 1 ? conc0 : 1);
+      p.tiles_x = sr::cdiv(p.W, 32);
+      p.tiles_y = p.H / 16;
+      const long long NT = (long long)p.tiles_x * p.tiles_y * d->n;
+      if (grid >= 1 && NT >= 24ll * grid && NT < (1ll << 30)) {  // (shorter strips: measured slower than the per-tile kernel)
+        p.cogs = d->n;
+        const int per = (int)((NT + grid - 1) / grid);
+        const int aux_kind = d->res1 ? 0 : d->res2 ? 1 : 2;
+        const bool prof = sr::prof_on();
+        if (prof) {
+          sr_launch_record r = {};
+          r.kernel_id = 64;
+          r.cin = d->cin_real > 0 ? d->cin_real : d->cin_pad;
+          r.cout = d->cout;
+          r.n = d->n;
+          r.h = p.H;
+          r.w = p.W;
+          const double px = (double)d->n * p.H * p.W;
+          r.flops = 2.0 * 9 * r.cin * r.cout * px;
+          r.bytes = 2.0 * ((double)d->n * p.in_h * p.in_w * r.cin + px * r.cout * (1 + naux));
+          sr::prof_begin(stream, r);
+        }
+        int rc = SR_OK;
+        auto go = [&](auto kern, int lds) {
+          rc = sr::ensure_dynamic_lds((const void*)kern, lds);
+          if (rc == SR_OK) hipLaunchKernelGGL(kern, dim3((unsigned)sr::cdiv((int)NT, per)), dim3(512), lds, stream, p, per, aux_kind);
+        };
+        switch (p.cin_blocks * 2 + (naux ? 1 : 0)) {
+          case 2: go(conv_stream_bf16_kernel<2, 1, false>, st::Cfg<2, 1, false>::LDS_BYTES); break;
+          case 3: go(conv_stream_bf16_kernel<2, 1, true>, st::Cfg<2, 1, true>::LDS_BYTES); break;
+          case 4: go(conv_stream_bf16_kernel<2, 2, false>, st::Cfg<2, 2, false>::LDS_BYTES); break;
+          case 5: go(conv_stream_bf16_kernel<2, 2, true>, st::Cfg<2, 2, true>::LDS_BYTES); break;
+          case 6: go(conv_stream_bf16_kernel<2, 3, false>, st::Cfg<2, 3, false>::LDS_BYTES); break;
+          case 7: go(conv_stream_bf16_kernel<2, 3, true>, st::Cfg<2, 3, true>::LDS_BYTES); break;
+          case 8: go(conv_stream_bf16_kernel<2, 4, false>, st::Cfg<2, 4, false>::LDS_BYTES); break;
+          default: go(conv_stream_bf16_kernel<2, 4, true>, st::Cfg<2, 4, true>::LDS_BYTES); break;
+        }
+        if (prof) sr::prof_end(stream);
+        if (rc) return rc;
+        SR_CHECK_LAUNCH("conv_stream_bf16 launch");
+        return SR_OK;
+      }
+    }
   }
   // Tile shape by launch size and depth.  Launches of >= 256 tiles with Cin <= 256 (the dense blocks, the head) use 16-row
   // tiles on 8 waves: 57 KB of LDS, so two workgroups share a CU and one's prologue / epilogue (no loads in flight for the
