@@ -990,9 +990,9 @@ extern "C" const char* sr_kernel_name(int id) {
   }
   if (id == 40) return "wgrad_rdb_bf16_kernel";
   if (id == 64) return "conv_stream_bf16_kernel";
-  if (id == 60) return "rdb_fused_bf16_kernel<0>";
-  if (id == 61) return "rdb_fused_bf16_kernel<1>";
-  if (id == 62) return "rdb_fused_bf16_kernel<2>";
+  if (id == 60) return "rdb_fused_bf16_kernelILi0E";
+  if (id == 61) return "rdb_fused_bf16_kernelILi1E";
+  if (id == 62) return "rdb_fused_bf16_kernelILi2E";
   if (id == 50) return "conv_fewcout_bf16_kernel";
   if (id == 42) return "conv_bf16_kernelILi1ELi1ELi4ELb0E";
   if (id == 43) return "conv_bf16_kernelILi2ELi1ELi4ELb0E";

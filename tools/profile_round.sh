@@ -45,4 +45,6 @@ bash $R/tools/pmc_sq.sh fp32 ${TAG}_fp32 > $O/sq_fp32.log 2>&1 && cp $R/gpurun_o
 bash $R/tools/pmc_sq.sh bf16 ${TAG}_bf16 > $O/sq_bf16.log 2>&1 && cp $R/gpurun_out/pmc_sq_${TAG}_bf16.txt $R/profiles/${TAG}_pmc_sq_bf16.txt
 find $R/gpurun_out -name "*_results.db" -size +8M -delete
 find $R/gpurun_out -name "*kernel_trace.csv" -delete
+# gpurun brings back gpurun_out/ only: the summaries travel in a copy of profiles/ (copy it over profiles/ afterwards)
+rm -rf $R/gpurun_out/profiles_out && mkdir -p $R/gpurun_out/profiles_out && cp $R/profiles/${TAG}_* $R/profiles/traffic*.json $R/profiles/mfma_util*.json $R/gpurun_out/profiles_out/
 du -sh $R/gpurun_out $R/profiles

@@ -37,7 +37,7 @@ def traffic(out, dbs):
     for i in range(0, len(dbs), 2):
         fetch, write = counter_means(dbs[i], 'FETCH_SIZE'), counter_means(dbs[i + 1], 'WRITE_SIZE')
         for k in fetch:
-            if k in write and any(t in k for t in ('conv_', 'wgrad')):
+            if k in write and any(t in k for t in ('conv_', 'wgrad', 'rdb_')):
                 res[mangled_like(k)] = int((2 * fetch[k] + write[k]) * 1024)
     add_aliases(res)
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
@@ -72,7 +72,7 @@ def mfma(out, dbs):
     for i in range(0, len(dbs), 2):
         busy, gui = per_dispatch(dbs[i], 'SQ_VALU_MFMA_BUSY_CYCLES', 'sum'), per_dispatch(dbs[i + 1], 'GRBM_GUI_ACTIVE', 'max')
         for k in busy:
-            if k in gui and any(t in k for t in ('conv_', 'wgrad')):
+            if k in gui and any(t in k for t in ('conv_', 'wgrad', 'rdb_')):
                 res[mangled_like(k)] = {'mfma_util': round(busy[k] / (gui[k] / 8 * 1024), 4), 'cycles_per_launch': int(gui[k] / 8)}
     add_aliases(res)
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
