@@ -202,6 +202,7 @@ SIGNATURES.update({
     'sr_conv3x3_chain_sync_ints': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'sr_conv3x3_chain_bf16': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'sr_set_conv_chain': (C.c_int, [C.c_int]),
+    'sr_chain_watchdog': (C.c_int, []),
     'sr_conv3x3_chain_f32': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'sr_set_conv_chain_f32': (C.c_int, [C.c_int]),
     'sr_patch_augment_u8_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -157,6 +157,54 @@ SideStreams& side_streams() {  // one set per (thread, device): streams and even
   return per_device[dev];
 }
 }  // namespace sr
+// ---- hand-off watchdog: a dense-block launch whose tiles waited for each other in vain raises the abort word of its sync block
+// (bounded spins: it never hangs, but what it wrote is invalid).  The whole-network drivers copy those words into pinned host memory
+// behind their launches (asynchronously: nothing waits) and look at the copies of EARLIER calls when they are entered, so a
+// time-out — a GPU shared with another process, CUs withheld from this one — surfaces as an error on the next call instead of as
+// silently wrong images.  sr_chain_watchdog() reports and clears it at any time (after a synchronisation: for the work before it).
+namespace {
+struct Watch {
+  int32_t* host = nullptr;  // kSlots pinned words
+  int next = 0;
+  static constexpr int kSlots = 64;
+};
+Watch& watch_of_device() {
+  thread_local std::map<int, Watch> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Watch& w = per_device[dev];
+  if (!w.host && hipHostMalloc((void**)&w.host, Watch::kSlots * sizeof(int32_t), hipHostMallocDefault) == hipSuccess)
+    for (int i = 0; i < Watch::kSlots; ++i) w.host[i] = 0;
+  return w;
+}
+}  // namespace
+namespace sr {
+void chain_watch(const int32_t* abort_word, hipStream_t stream) {
+  Watch& w = watch_of_device();
+  if (!w.host || !abort_word) return;
+  const int slot = w.next;
+  w.next = (w.next + 1) % Watch::kSlots;
+  (void)hipMemcpyAsync(w.host + slot, abort_word, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+}
+int chain_check(const char* who) {
+  Watch& w = watch_of_device();
+  if (!w.host) return SR_OK;
+  bool hit = false;
+  for (int i = 0; i < Watch::kSlots; ++i)
+    if (((volatile int32_t*)w.host)[i] != 0) {
+      hit = true;
+      w.host[i] = 0;
+    }
+  if (!hit) return SR_OK;
+  set_error("%s: an earlier dense-block launch timed out waiting for a neighbour tile (are all CUs of the GPU available to this "
+            "process?); its results were invalid", who);
+  return SR_ELAUNCH;
+}
+}  // namespace sr
+extern "C" int sr_chain_watchdog(void) { return sr::chain_check("sr_chain_watchdog"); }
+// Development hook (tests): queue a copy of one device word the way the network drivers queue their abort words.
+extern "C" void sr_dev_chain_watch(const int32_t* word, void* stream) { sr::chain_watch(word, (hipStream_t)stream); }
+
 extern "C" int sr_set_forward_groups(int groups) {
   SR_CHECK_ARG(groups >= 0 && groups <= 4, "sr_set_forward_groups: 0 (automatic) or 1..4");
   g_forward_groups = groups;

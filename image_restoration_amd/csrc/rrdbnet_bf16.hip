@@ -272,6 +272,7 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
   SR_CHECK_ARG(h_in % P.unshuffle == 0 && w_in % P.unshuffle == 0, "%s: input not divisible by %d", who, P.unshuffle);
   SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "%s: workspace must be 256-byte aligned", who);
   const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  if (int rc = sr::chain_check(who)) return rc;  // a hand-off time-out of an earlier call (capi.hip)
   const FwdSpaceH W = carve_fwd_h(cfg, P, n, h, w, (char*)workspace, train);
   if (W.bytes > workspace_bytes) {
     sr::set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, W.bytes);
@@ -289,13 +290,19 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
     sr::set_error("%s: sync memset failed", who);
     return SR_ELAUNCH;
   }
-  if (groups <= 1 || sr::prof_on()) return forward_body_h(cfg, P, W, packed, x, y, n, h, w, stream, train, who, W.sync);
+  if (groups <= 1 || sr::prof_on()) {
+    const int rc = forward_body_h(cfg, P, W, packed, x, y, n, h, w, stream, train, who, W.sync);
+    sr::chain_watch(W.sync, stream);
+    return rc;
+  }
   const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
   const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
-  return sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
+  const int rc = sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
     return forward_body_h(cfg, P, shift_space_h(P, W, n0, h, w), packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train,
                           who, W.sync + (size_t)(g % kSyncBlocks) * W.sync_ints);
   });
+  for (int g = 0; g < groups && g < kSyncBlocks; ++g) sr::chain_watch(W.sync + (size_t)g * W.sync_ints, stream);
+  return rc;
 }
 }  // namespace
 
@@ -408,6 +415,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   SR_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)saved % 256 == 0,
                "sr_rrdbnet_backward_bf16: workspaces must be 256-byte aligned");
   const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  if (int rcw = sr::chain_check("sr_rrdbnet_backward_bf16")) return rcw;
   const FwdSpaceH S = carve_fwd_h(cfg, P, n, h, w, (char*)saved, true);
   const BwdSpaceH B = carve_bwd_h(cfg, P, n, h, w, (char*)workspace);
   if (S.bytes > saved_bytes || B.bytes > workspace_bytes) {
@@ -581,5 +589,6 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     rc = sr_cb16_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
     if (rc) return rc;
   }
+  sr::chain_watch(B.sync, stream);
   return SR_OK;
 }

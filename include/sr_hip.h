@@ -236,6 +236,11 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
 size_t sr_conv3x3_chain_sync_ints(int n, int h, int w);
 int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);
 int sr_set_conv_chain(int enabled);
+/* Hand-off watchdog: SR_ELAUNCH (with a message) if a dense-block launch issued by sr_rrdbnet_*_bf16 on this thread and device timed
+ * out waiting for a neighbour tile since the last check — its output was invalid; SR_OK otherwise.  The network entry points run the
+ * same check when they are entered (on the abort words they copied to pinned host memory behind their earlier launches, without
+ * synchronising), so a time-out surfaces on the next call at the latest; call this after a synchronisation to cover the work before it. */
+int sr_chain_watchdog(void);
 /* fp32 twin: same contract and sync block layout; the calls that share a block must be chains of the same shape (cout of every
  * conv), and a block is used by one precision at a time. */
 int sr_conv3x3_chain_f32(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);

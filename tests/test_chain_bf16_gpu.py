@@ -172,3 +172,24 @@ def test_transposed_block_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, m
         assert int(sync[0]) == 0
         assert torch.equal(cat_a.buf, cat_b.buf), rep
         assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
+
+
+def test_handoff_watchdog_reports_a_raised_abort_word_once(cuda):
+    """A dense-block launch whose tiles waited in vain raises its sync block's abort word; the network drivers copy those words to
+    pinned host memory behind their launches and sr_chain_watchdog / the next driver call turns a raised one into an error
+    (here: the plumbing, with a word raised by hand — a real time-out needs a GPU that withholds CUs)."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.sr_dev_chain_watch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sr_dev_chain_watch.restype = None
+    assert lib.sr_chain_watchdog() == 0
+    word = torch.zeros(4, dtype=torch.int32, device=cuda)
+    lib.sr_dev_chain_watch(word.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert lib.sr_chain_watchdog() == 0
+    word[0] = 1
+    torch.cuda.synchronize()
+    lib.sr_dev_chain_watch(word.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert lib.sr_chain_watchdog() < 0 and b'timed out' in lib.sr_last_error()
+    assert lib.sr_chain_watchdog() == 0
