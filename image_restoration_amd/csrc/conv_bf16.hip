@@ -809,7 +809,10 @@ static_assert(LDS_BYTES <= 160 * 1024, "fused dense block: LDS");
 constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
 constexpr int MAXSTEPS = 80, MAXP = 480;
 constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
-constexpr int AR = 4;    // ring of weight fragments in registers: read AR-1 fragments ahead of their MFMAs
+#ifndef SR_FZ_AR
+#define SR_FZ_AR 4
+#endif
+constexpr int AR = SR_FZ_AR;  // ring of weight fragments in registers: read AR-1 fragments ahead of their MFMAs
 
 struct StepD {
   int in, chunk, g0, ng, dx0, ndx, tb;
@@ -1092,8 +1095,10 @@ struct Env {
 // -> out of range, bank swizzle as in conv_tile_h) are recomputed at every issue — ~60 vector instructions, six times per round —
 // rather than kept in five registers for the whole kernel.
 template <int AUX>
-__device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0) {
-  const int lane = e.tid & 63;
+__device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0, const int x0,
+                                                const int y0) {
+  int lane = e.tid & 63;
+  asm volatile("" : "+v"(lane));  // (or the lane-only parts of the five offsets are hoisted out of the tile loop and spilled)
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int u = r * NW + e.wave;
@@ -1101,7 +1106,7 @@ __device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buf
     const int q = pc * 64 + lane;
     const int pix = q >> 1, half = q & 1;
     const int row = pix / XROW, col = pix - row * XROW;
-    const int gy = e.y0 - 1 + row, gx = e.x0 - 1 + col;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool valid = pix < XPIX && gy >= 0 && gy < e.H && gx >= 0 && gx < e.W;
     const unsigned vo = valid ? (unsigned)((gy * e.W + gx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, vo,
@@ -1351,7 +1356,7 @@ __device__ __forceinline__ void stamp(const Env& e, int i) {
 
 template <int S, int MODE>
 __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                        const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
+                                        const __amdgpu_buffer_rsrc_t w_rs) {
   constexpr StepD d = kS.st[S];
   // the lane address bases pass through an empty asm at every step: derived addresses (tile buffer + column offset ...) are then
   // computed where they are used instead of being hoisted out of the round loop into two dozen permanently live registers
@@ -1364,9 +1369,11 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
       wait_vm<step_Kflag<MODE, S>()>();  // the flag fetch of a few steps ago has landed
       bool gave_up = false;
       const int lane = e.tid & 63;
-      if (e.fvo != 0xfffffff0u) {
+      unsigned fvo = e.fvo;
+      asm volatile("" : "+v"(fvo));  // (the slow path's address is computed here, not kept in registers — or scratch — from the tile's start)
+      if (fvo != 0xfffffff0u) {
         const int want = P.epoch + d.tile_in;
-        const int* flag_ptr = P.done + e.n * (P.tiles_x * P.tiles_y) + (e.fvo >> 2);
+        const int* flag_ptr = P.done + e.n * (P.tiles_x * P.tiles_y) + (fvo >> 2);
         int v = *(volatile lds_int_p)(e.smem + LDS_FLAGS + lane * 4), spins = 0;
         while (v < want) {
           __builtin_amdgcn_s_sleep(2);
@@ -1395,13 +1402,24 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   }
   if constexpr (d.tile_in > 0) {
     if (*(volatile lds_int_p)e.ctl) return false;
-    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in));  // agent scope: written by other workgroups of this launch
+    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in), e.x0, e.y0);  // agent scope: written by other workgroups of this launch
   }
   issue_wgroups<d.q0, d.q1>(e, w_rs);
-  if constexpr (d.nx_tile > 0) issue_tile_pair<0>(e, nx_rs, 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1));
+  if constexpr (d.nx_tile > 0) {  // the workgroup's next tile (behind the last one: an empty descriptor = zeros, no traffic)
+    const int T = P.tiles_x * P.tiles_y, gn = e.tile + (int)gridDim.x;
+    const bool more = gn < P.n * T;
+    const int nn = more ? gn / T : 0, tn = more ? gn - nn * T : 0, tyn = tn / P.tiles_x;
+    const char* in0 = kernarg_at<const char*>(offsetof(ConvParamsH, in));
+    const long long nb0 = kernarg_at<long long>(offsetof(ConvParamsH, in_nb));
+    issue_tile_pair<0>(e, make_rsrc(in0 + nn * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
+                       (tn - tyn * P.tiles_x) * 32, tyn * TH);
+  }
   issue_wgroups<d.nx_q0, d.nx_q1>(e, w_rs);
   if constexpr (d.flag_in > 0) {
-    if (e.wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
+    if (e.wave == 0) {
+      const int T = P.tiles_x * P.tiles_y;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(P.done + e.n * T, (unsigned)T * 4u), (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
+    }
   }
   if constexpr (MODE != 0 && d.first_of_in == 4) {  // conv5's residual sources: 16 loads per wave that land under the last input's MFMAs
     const char* r1 = kernarg_at<const char*>(offsetof(FusedParams, res1));
@@ -1464,10 +1482,10 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
 
 template <int S, int MODE>
 __device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                          const __amdgpu_buffer_rsrc_t w_rs, const __amdgpu_buffer_rsrc_t f_rs, const __amdgpu_buffer_rsrc_t nx_rs) {
+                                          const __amdgpu_buffer_rsrc_t w_rs) {
   if constexpr (S < kS.nsteps) {
-    if (!do_step<S, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs)) return false;
-    return run_steps<S + 1, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs);
+    if (!do_step<S, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) return false;
+    return run_steps<S + 1, MODE>(e, acc, o, R, M, P, x_rs, w_rs);
   } else {
     return true;
   }
@@ -1510,35 +1528,41 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     const float* b = P.lv[k].bias;
     ((float*)(smem + LDS_BIAS))[e.tid] = (b && i < (k < 4 ? 32 : 64)) ? b[i] : 0.f;
   }
-  const int T = P.tiles_x * P.tiles_y;
-  const int slot = blockIdx.x / T;
-  int t = blockIdx.x - slot * T;
-  const int tx = t % P.tiles_x, ty = t / P.tiles_x;
-  const int x0 = tx * 32, y0 = ty * TH;
-  e.x0 = x0;
-  e.y0 = y0;
-  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
-  int nb = -1;
-  if (e.wave == 0 && lane < 9) {
-    const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
-    if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) nb = ny * P.tiles_x + nx;
+  // Tiles of the whole batch in image-major, row-major order; workgroup b takes tiles b, b + G, b + 2G, ... (G = grid).  Every
+  // workgroup walks its tiles in increasing order, so the tiles in flight are always a window [m, m + G) of that order, m = the
+  // smallest unfinished tile: a tile's dependencies (its 8 neighbours, at most one row of tiles ahead, per conv) are then running or
+  // finished as long as the window holds the ~5 rows a block's hand-offs can keep blocked (the host checks G >= 6 tiles_x + 2) —
+  // no other co-residency is assumed, images may have more tiles than the chip has CUs.
+  const int T = P.tiles_x * P.tiles_y, G = gridDim.x, NT = P.n * T;
+  if (e.dbg && e.tid == 0) {  // absolute clocks (comparable inside an XCD) of this workgroup's start ...
+    e.dbg[60] = __builtin_readcyclecounter();
+    e.dbg[62] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
   }
-  e.fvo = nb >= 0 ? (unsigned)nb * 4u : 0xfffffff0u;
   for (int round = 0;; ++round) {
-    e.n = round * P.ipr + slot;
-    if (e.n >= P.n) break;
-    e.tile = e.n * T + ty * P.tiles_x + tx;
+    const int gt = round * G + blockIdx.x;
+    if (gt >= NT) break;
+    e.n = gt / T;
+    const int t = gt - e.n * T;
+    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    e.x0 = tx * 32;
+    e.y0 = ty * TH;
+    e.tile = gt;
+    {  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
+      int nb = -1;
+      if (e.wave == 0 && lane < 9) {
+        const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+        if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) nb = ny * P.tiles_x + nx;
+      }
+      e.fvo = nb >= 0 ? (unsigned)nb * 4u : 0xfffffff0u;
+    }
     e.xin = p0.in + (long long)e.n * p0.in_nb;
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(e.xin, 12u * e.plane_b);
-    const __amdgpu_buffer_rsrc_t f_rs = make_rsrc(P.done + e.n * T, (unsigned)T * 4u);
-    // the x tile and the first weight groups of a round are issued during the previous round (make_sched: nx_tile, nx_q*); behind the
-    // last image the descriptor is empty (zeros, no traffic).  Same instructions in the same order before the first round.
-    const bool more = e.n + P.ipr < P.n;
-    const __amdgpu_buffer_rsrc_t nx_rs = make_rsrc(p0.in + (long long)(more ? e.n + P.ipr : 0) * p0.in_nb, more ? 12u * e.plane_b : 0u);
+    // (the x chunks and the first weight groups of the next tile are issued during this one — make_sched: nx_tile, nx_q* —, the same
+    // instructions in the same order before the first tile)
     if (round == 0) {
       __syncthreads();  // s_ctl, the biases and the weight-offset table are set
-      issue_tile_pair<0>(e, x_rs, 0, 0);
-      issue_tile_pair<0>(e, x_rs, 2, 2);
+      issue_tile_pair<0>(e, x_rs, 0, 0, e.x0, e.y0);
+      issue_tile_pair<0>(e, x_rs, 2, 2, e.x0, e.y0);
       issue_wgroups<0, kS.q_ahead>(e, w_rs);
     }
     stamp(e, 0);
@@ -1547,9 +1571,10 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     Ops o;
     ResRegs R;
     MaskRegs M;
-    if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs, f_rs, nx_rs)) break;
+    if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) break;
     stamp(e, 42);
   }
+  if (e.dbg && e.tid == 0) e.dbg[61] = __builtin_readcyclecounter();  // ... and end
   fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
 }
 
@@ -1976,6 +2001,9 @@ static int g_chain_enabled = 3;  // 0 off, 1 = 32-row ring tiles (one workgroup 
 static long long* g_chain_clocks = nullptr;
 // Development aid (tools/chain_phase.py; not part of the ABI): per work item, wave 0 writes claim / wait / acquire / tile / drain clocks.
 extern "C" void sr_dev_chain_phase_clocks(void* buf) { g_chain_clocks = (long long*)buf; }
+namespace sr {
+int chain_mode() { return g_chain_enabled; }
+}
 extern "C" int sr_set_conv_chain(int enabled) {
   g_chain_enabled = enabled;
   return SR_OK;
@@ -2024,7 +2052,11 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   const int avail = cu_count[dev] / (conc > 1 ? conc : 1);
   const int tiles_x = sr::cdiv(w, 32), tiles_y = h / 16;
   const int T = tiles_x * tiles_y;
-  if (T > avail) return SR_OK;  // an image's tiles wait for each other: they must all be resident
+  // the tiles in flight are a window of the row-major tile order (see the kernel): it must hold the rows a block's hand-offs can block
+  const long long NT = (long long)T * n;
+  const int grid = (int)(NT < avail ? NT : avail);
+  if (grid < NT && grid < 6 * tiles_x + 2) return SR_OK;
+  if (NT >= (1ll << 30)) return SR_OK;
   fz::FusedParams P = {};
   const char* lo = (const char*)d[0].wpacked;
   for (int k = 1; k < 5; ++k)
@@ -2044,7 +2076,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.wbase = lo;
   P.wspan = (unsigned)span;
   P.n = n;
-  P.ipr = avail / T < n ? avail / T : n;
+  P.ipr = 0;  // (unused: the grid is any number of workgroups <= CUs)
   P.tiles_x = tiles_x;
   P.tiles_y = tiles_y;
   P.abort = sync;
@@ -2095,11 +2127,11 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     sr::prof_begin(stream, r);
   }
   if (lean)
-    hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
   else if (back)
-    hipLaunchKernelGGL(rdb_fused_bf16_kernel<2>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<2>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
   else
-    hipLaunchKernelGGL(rdb_fused_bf16_kernel<0>, dim3((unsigned)(P.ipr * T)), dim3(512), fz::LDS_BYTES, stream, P);
+    hipLaunchKernelGGL(rdb_fused_bf16_kernel<0>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
   if (prof) sr::prof_end(stream);
   SR_CHECK_LAUNCH("rdb_fused_bf16 launch");
   *launched = true;

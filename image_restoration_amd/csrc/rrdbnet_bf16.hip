@@ -285,6 +285,11 @@ int forward_h(const sr_rrdbnet_cfg* cfg, const void* packed, const float* x, flo
   if (groups == 0) groups = train ? 1 : 4;  // the training forward (one saved buffer per dense block) measured no gain
   const long long wg_per_image = (long long)sr::cdiv(w, 32) * sr::cdiv(h, 32);
   while (groups > 1 && (n / groups) * wg_per_image < 64) --groups;
+  // The fused dense-block kernel needs a window of ~6 tile rows in flight (conv_bf16.hip): on large images — the tiler's cells — a
+  // group's share of the CUs is too small for it, and one launch fills the chip by itself anyway.
+  if (sr::forward_groups() == 0 && sr::chain_mode() >= 3 && cfg->num_feat == 64 && cfg->num_grow_ch == 32 && h % 16 == 0 &&
+      6 * sr::cdiv(w, 32) + 2 > 256 / (groups > 1 ? groups : 1))
+    groups = 1;
   // hand-off words of the chain launches: zero once per forward, before the image groups fork
   if (hipMemsetAsync(W.sync, 0, W.sync_ints * kSyncBlocks * sizeof(int32_t), stream) != hipSuccess) {
     sr::set_error("%s: sync memset failed", who);

@@ -227,9 +227,9 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
  * the entry point does when the chain is not eligible (upsampling, NCHW output, > 64 couts, ragged height, small launches,
  * profiling) or when disabled.  sr_set_conv_chain(mode): 0 = off, 1 = 32-row ring tiles on one workgroup per CU, 2 = 16-row
  * tiles on two workgroups per CU, 3 (default) = the fused dense-block kernel where the five descriptors are one 64 + 4 x 32
- * channel block over a single concat buffer (a dense block, forward or transposed) and an image's 16x32 tiles fit the chip
- * together — one workgroup per tile keeps the partial sums of all unfinished convs in registers, every input is staged once —
- * and mode 2 otherwise.
+ * channel block over a single concat buffer (a dense block, forward or transposed) and six rows of 16x32 tiles fit the CUs the
+ * launch may use — one workgroup per tile keeps the partial sums of all unfinished convs in registers, every input is staged
+ * once, images may have more tiles than the chip has CUs — and mode 2 otherwise.
  *   sync        device int32[sr_conv3x3_chain_sync_ints(n, h, w)], zeroed by the caller (hipMemsetAsync) before the first call that
  *               uses it; calls sharing a block pass increasing call_index 0, 1, 2, ... < 256 and the same n / h / w
  *   sync[0]     is raised by the kernel if a wait on a dependency timed out (bounded spins: never a hang) */

@@ -61,7 +61,9 @@ def _fresh(dev, n, nf, gc, h, w, seed):
     (2, 64, 40, 64, 32),       # small launch: conv-by-conv fallback inside the entry point
     (12, 120, 128, 64, 32),    # height not a multiple of 32: fallback
     (20, 128, 128, 64, 32),    # fused kernel: three rounds of 8 images, the last one partly empty
-    (5, 208, 96, 64, 32),      # fused kernel: 39 tiles per image, 6 images per round
+    (5, 208, 96, 64, 32),      # fused kernel: 39 tiles per image, a window of 195 tiles
+    (2, 544, 544, 64, 32),     # fused kernel: a tiler cell = 578 tiles per image, more than CUs: the window slides down the image
+    (3, 320, 1088, 64, 32),    # fused kernel: 34 tiles per row, 680 per image
 ])
 @pytest.mark.parametrize('mode', [1, 2, 3])
 def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):

@@ -89,3 +89,4 @@ if __name__ == '__main__':
     bench(4, 128, 128)
     bench(32, 128, 128)
     bench(4, 544, 544, iters=10)
+    bench(1, 544, 544, iters=10)

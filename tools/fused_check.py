@@ -15,7 +15,7 @@ ok = True
 MODE = int(os.environ.get('FUSED_MODE', '3'))
 CFGS = [(8, 128, 128), (16, 128, 128), (3, 64, 64), (12, 160, 100), (20, 128, 128), (24, 128, 128), (20, 128, 128)]
 if os.environ.get('STRESS'):
-    CFGS = [(16, 128, 128), (20, 128, 128), (12, 160, 100)] * 4
+    CFGS = [(16, 128, 128), (20, 128, 128), (12, 160, 100), (4, 544, 544), (3, 320, 1088)] * 3
 for (n, h, w) in CFGS:
     nf, gc = 64, 32
     packs = _rdb(dev, nf, gc, 3)

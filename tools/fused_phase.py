@@ -44,6 +44,15 @@ def run(n, h, w, nf=64, gc=32):
         med, mx = float(rel[:, i].median()), float(rel[:, i].max())
         print(f'  {NAMES[i]:22s} {med:7.0f} {mx:7.0f}   (+{med - prev:6.0f})')
         prev = med
+    xcd = t[:, 62].long() & 15
+    for x in sorted(set(xcd.tolist())):
+        sel = xcd == x
+        st, en = t[sel, 60], t[sel, 61]
+        ok = (st > 0) & (en > st)
+        st, en = st[ok], en[ok]
+        s0 = st.min()
+        print(f'  XCD {x}: {int(ok.sum())} workgroups; starts +{float((st - s0).median()):.0f} (median) +{float((st - s0).max()):.0f} (last); ends '
+              f'+{float((en - s0).min()):.0f} (first) +{float((en - s0).median()):.0f} (median) +{float((en - s0).max()):.0f} (last); own duration median {float((en - st).median()):.0f}')
 
 
 if __name__ == '__main__':
