@@ -1044,7 +1044,8 @@ struct FusedParams {
   unsigned wdelta[5];  // byte offset of conv k's packed image from wbase
   const char* wbase;
   unsigned wspan;      // bytes covered by the five images from wbase
-  int n, ipr, tiles_x, tiles_y;  // images, images per round, tile grid of an image
+  int n, ipr, tiles_x, tiles_y;  // images, (unused), tile grid of an image
+  int g_dn, g_dty, g_dtx;        // the grid size G as a step of the tile cursor: G = (g_dn tiles_y + g_dty) tiles_x + g_dtx
   int* done;
   int* abort;
   int epoch;
@@ -1081,6 +1082,7 @@ struct Env {
   lds_int_p ctl;       // LDS word: a dependency wait timed out
   int wave, tid;
   int n, tile, x0, y0;  // image, tile of the batch, first column / row of the tile
+  unsigned xpk[5];     // per tile piece of this wave: pixel row | column << 8 | swizzle bit << 16 | inside the tile << 17
   unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
   unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
   unsigned plane_b;
@@ -1091,27 +1093,41 @@ struct Env {
   long long* dbg;
 };
 
-// Two chunks of a tile = 40 pieces of 1 KB, five per wave.  The lane offsets (pixel -> byte offset inside a channel-block plane, padding
-// -> out of range, bank swizzle as in conv_tile_h) are recomputed at every issue — ~60 vector instructions, six times per round —
-// rather than kept in five registers for the whole kernel.
+// Two chunks of a tile = 40 pieces of 1 KB, five per wave.  What depends on the lane only (row and column of its pixel inside the
+// tile, bank-swizzle bit, padding) is packed into one register per piece at kernel start (Env::xpk); the byte offsets inside a
+// channel-block plane (padding -> out of range) are finished at every issue from the tile's origin: ~12 vector instructions per
+// piece.  (Unpacked, hipcc hoisted the lane-only parts out of the tile loop into ~20 registers and spilled; recomputed from the
+// lane id at every issue they cost ~800 cycles in front of the step's MFMAs, six times per tile.)
 template <int AUX>
 __device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0, const int x0,
                                                 const int y0) {
-  int lane = e.tid & 63;
-  asm volatile("" : "+v"(lane));  // (or the lane-only parts of the five offsets are hoisted out of the tile loop and spilled)
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int u = r * NW + e.wave;
     const int ci = u >= XU ? 1 : 0, pc = u - ci * XU;
-    const int q = pc * 64 + lane;
-    const int pix = q >> 1, half = q & 1;
-    const int row = pix / XROW, col = pix - row * XROW;
-    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-    const bool valid = pix < XPIX && gy >= 0 && gy < e.H && gx >= 0 && gx < e.W;
-    const unsigned vo = valid ? (unsigned)((gy * e.W + gx) * 32 + (half ^ ((col >> 3) & 1)) * 16) : 0xfffffff0u;
+    unsigned pk = e.xpk[r];
+    asm volatile("" : "+v"(pk));
+    const int gy = y0 - 1 + (int)(pk & 0xffu), gx = x0 - 1 + (int)((pk >> 8) & 0xffu);
+    const bool valid = (pk >> 17) != 0u && gy >= 0 && gy < e.H && gx >= 0 && gx < e.W;
+    const unsigned vo = valid ? (unsigned)((gy * e.W + gx) * 32) + ((pk >> 12) & 16u) : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, vo,
                                              (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
   }
+}
+
+// The tile G positions behind (n, ty, tx) in image-major, row-major order — additions and two carries instead of two divisions.
+__device__ __forceinline__ void tile_step(const FusedParams& P, int& n, int& ty, int& tx) {
+  tx += P.g_dtx;
+  if (tx >= P.tiles_x) {
+    tx -= P.tiles_x;
+    ++ty;
+  }
+  ty += P.g_dty;
+  if (ty >= P.tiles_y) {
+    ty -= P.tiles_y;
+    ++n;
+  }
+  n += P.g_dn;
 }
 
 template <int Q>
@@ -1150,8 +1166,8 @@ __device__ __forceinline__ void load_a(const Env& e, Ops& o, const int lf) {  //
   constexpr StepD d = kS.st[S];
   o.a[(3 * d.uc0 + lf) % AR] = *(const bf16x8*)(e.smem + LDS_W0 + e.wlane + ((d.wp0 + lf) % RING) * 1024);
 }
-template <int S>
-__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT], Ops& o) {
+template <int S, class Issue>
+__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT], Ops& o, Issue&& issue) {
   constexpr StepD d = kS.st[S];
   constexpr int NU = d.ndx * d.ng, NF = 3 * NU;
   constexpr bool next_pre = S + 1 < kS.nsteps && kS.st[S + 1 < kS.nsteps ? S + 1 : S].pre;
@@ -1181,6 +1197,10 @@ __device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT]
       for (int r = 0; r < PT; ++r)
         acc[g][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[(3 * d.uc0 + lf) % AR], o.bx[(d.dc0 + dxi) & 1][r + dy], acc[g][r], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (lf == 0) {
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 }
@@ -1402,17 +1422,22 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   }
   if constexpr (d.tile_in > 0) {
     if (*(volatile lds_int_p)e.ctl) return false;
-    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in), e.x0, e.y0);  // agent scope: written by other workgroups of this launch
   }
+  // Everything this step issues to memory, in the order the counted waits assume.  It runs BEHIND the step's first MFMAs (operands
+  // read ahead), so its scalar / vector work — offset table reads, lane offsets of tile pieces, descriptors — sits in the matrix
+  // pipe's shadow instead of between the barrier and the first MFMA.
+  auto issue_all = [&]() {
+  if constexpr (d.tile_in > 0)
+    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in), e.x0, e.y0);  // agent scope: written by other workgroups of this launch
   issue_wgroups<d.q0, d.q1>(e, w_rs);
   if constexpr (d.nx_tile > 0) {  // the workgroup's next tile (behind the last one: an empty descriptor = zeros, no traffic)
-    const int T = P.tiles_x * P.tiles_y, gn = e.tile + (int)gridDim.x;
-    const bool more = gn < P.n * T;
-    const int nn = more ? gn / T : 0, tn = more ? gn - nn * T : 0, tyn = tn / P.tiles_x;
+    int nn = e.n, tyn = e.y0 / TH, txn = e.x0 >> 5;
+    tile_step(P, nn, tyn, txn);
+    const bool more = nn < P.n;
     const char* in0 = kernarg_at<const char*>(offsetof(ConvParamsH, in));
     const long long nb0 = kernarg_at<long long>(offsetof(ConvParamsH, in_nb));
-    issue_tile_pair<0>(e, make_rsrc(in0 + nn * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
-                       (tn - tyn * P.tiles_x) * 32, tyn * TH);
+    issue_tile_pair<0>(e, make_rsrc(in0 + (more ? nn : 0) * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
+                       txn * 32, tyn * TH);
   }
   issue_wgroups<d.nx_q0, d.nx_q1>(e, w_rs);
   if constexpr (d.flag_in > 0) {
@@ -1439,6 +1464,7 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  };
   if constexpr (d.post > 0 && d.post < 5) stamp(e, 2 + 8 * (d.post - 1));  // last step of conv `post` runs
   if constexpr (d.post == 5) stamp(e, 40);
 #pragma unroll
@@ -1449,7 +1475,7 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][r][i] = 0.f;
     }
-  compute_step<S>(e, acc, o);
+  compute_step<S>(e, acc, o, issue_all);
   typedef const __attribute__((address_space(3))) float* lds_float_p;
   if constexpr (MODE == 1 && d.post > 0 && d.post < 5) {
     epi_mid_lean<d.post - 1>(e, acc[d.post - 1], x_rs, kernarg_at<float>(offsetof(FusedParams, slope)));
@@ -1521,6 +1547,15 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     const unsigned dlt = k == 0 ? P.wdelta[0] : k == 1 ? P.wdelta[1] : k == 2 ? P.wdelta[2] : k == 3 ? P.wdelta[3] : P.wdelta[4];
     ((unsigned*)(smem + LDS_WTAB))[e.tid] = dlt + (t & 0x0fffffffu);
   }
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int u = r * NW + e.wave;
+    const int pc = u >= XU ? u - XU : u;
+    const int q = pc * 64 + lane;
+    const int pix = q >> 1, half = q & 1;
+    const int row = pix / XROW, col = pix - row * XROW;
+    e.xpk[r] = (unsigned)row | (unsigned)col << 8 | (unsigned)(half ^ ((col >> 3) & 1)) << 16 | (pix < XPIX ? 1u << 17 : 0u);
+  }
   const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(P.wbase, P.wspan);
   if (e.tid == 0) s_ctl = 0;
   if (e.tid < 5 * 64) {  // the five packed biases (conv1-4: 32 floats, conv5: 64; zeros when a conv has none)
@@ -1533,20 +1568,26 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
   // smallest unfinished tile: a tile's dependencies (its 8 neighbours, at most one row of tiles ahead, per conv) are then running or
   // finished as long as the window holds the ~5 rows a block's hand-offs can keep blocked (the host checks G >= 6 tiles_x + 2) —
   // no other co-residency is assumed, images may have more tiles than the chip has CUs.
-  const int T = P.tiles_x * P.tiles_y, G = gridDim.x, NT = P.n * T;
+  const int T = P.tiles_x * P.tiles_y;
   if (e.dbg && e.tid == 0) {  // absolute clocks (comparable inside an XCD) of this workgroup's start ...
     e.dbg[60] = __builtin_readcyclecounter();
     e.dbg[62] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
   }
+  int cn = 0, cty = 0, ctx = 0;  // this workgroup's tile: image, tile row, tile column (the first one: two divisions, then tile_step)
+  {
+    const int b = blockIdx.x;
+    cn = b / T;
+    const int t = b - cn * T;
+    cty = t / P.tiles_x;
+    ctx = t - cty * P.tiles_x;
+  }
   for (int round = 0;; ++round) {
-    const int gt = round * G + blockIdx.x;
-    if (gt >= NT) break;
-    e.n = gt / T;
-    const int t = gt - e.n * T;
-    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    if (cn >= P.n) break;
+    e.n = cn;
+    const int ty = cty, tx = ctx;
     e.x0 = tx * 32;
     e.y0 = ty * TH;
-    e.tile = gt;
+    e.tile = (cn * P.tiles_y + ty) * P.tiles_x + tx;
     {  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
       int nb = -1;
       if (e.wave == 0 && lane < 9) {
@@ -1573,6 +1614,7 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     MaskRegs M;
     if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) break;
     stamp(e, 42);
+    tile_step(P, cn, cty, ctx);
   }
   if (e.dbg && e.tid == 0) e.dbg[61] = __builtin_readcyclecounter();  // ... and end
   fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
@@ -2076,7 +2118,10 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.wbase = lo;
   P.wspan = (unsigned)span;
   P.n = n;
-  P.ipr = 0;  // (unused: the grid is any number of workgroups <= CUs)
+  P.ipr = 0;
+  P.g_dn = grid / T;
+  P.g_dty = (grid % T) / tiles_x;
+  P.g_dtx = (grid % T) % tiles_x;
   P.tiles_x = tiles_x;
   P.tiles_y = tiles_y;
   P.abort = sync;
