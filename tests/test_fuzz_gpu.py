@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize('script,args', [('conv_fuzz.py', ['7', '40']), ('wgrad_fuzz.py', ['7', '30']), ('net_fuzz.py', ['7', '5']),
-                                         ('disc_fuzz.py', ['7', '4'])])
+                                         ('disc_fuzz.py', ['7', '4']), ('block_fuzz.py', ['7', '16'])])
 def test_fuzz_slice(cuda, script, args):
     r = subprocess.run([sys.executable, os.path.join(HERE, 'fuzz', script)] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
