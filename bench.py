@@ -154,6 +154,9 @@ def roofline_of(ks, peak_tflops, suffix=''):
     common = {'traffic': traffic, 'traffic_source': src, 'kernel': k0['kernel'], 'avg_launch_ms': k0['avg_ms'],
               'launches': k0['launches'], 'share_of_profiled_time': round(k0['total_ms'] / sum(k['total_ms'] for k in ks), 4),
               'mfma_util_pmc_stored': mfma_pmc}
+    if peak_tflops == PEAK_BF16_TFLOPS:
+        common['peak_note'] = ('nominal dense bf16 peak; a bare v_mfma_f32_32x32x16_bf16 loop on random data sustains 0.65-0.75 of it on this '
+                               'pool (tools/mfma_peak.hip, DESIGN.md section 7)')
     if mfma_frac >= hbm_frac:
         return dict({'bound': 'mfma', 'achieved': k0['tflops'], 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(mfma_frac, 4),
                      'hbm_frac_algorithmic': k0['hbm_frac']}, **common)
