@@ -793,8 +793,9 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 // scope (sc1: no cache invalidate).  The phases are ordered so that every hand-off (store -> publish -> flag -> halo fetch, ~4
 // memory round trips) runs under MFMAs that do not depend on it: after conv k's own phase come partial sums of later convs over
 // inputs that are already in the LDS (conv5's are deferred as far as its accumulation order allows).
-// A tile's workgroup waits for its 8 neighbours at every hand-off, so all tiles of an image must be resident together: the grid is
-// (images per round) x (tiles per image) <= CUs, and the host falls back to the chain kernel when an image has more tiles than CUs.
+// A tile's workgroup waits for its 8 neighbours at every hand-off.  Tiles are numbered image-major, row-major over the whole batch and
+// workgroup b of a grid of G <= CUs takes tiles b, b + G, ... in increasing order, so the tiles in flight are a window of that order
+// (see the kernel): the host only asks for G >= 6 tiles_x + 2 and falls back to the chain kernel otherwise.
 namespace fz {
 constexpr int NW = 8, PT = 2, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
 constexpr int XU = 20, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer (18 x 34 pixels x 32 B, rounded up)
@@ -1044,7 +1045,7 @@ struct FusedParams {
   unsigned wdelta[5];  // byte offset of conv k's packed image from wbase
   const char* wbase;
   unsigned wspan;      // bytes covered by the five images from wbase
-  int n, ipr, tiles_x, tiles_y;  // images, (unused), tile grid of an image
+  int n, tiles_x, tiles_y;       // images, tile grid of an image
   int g_dn, g_dty, g_dtx;        // the grid size G as a step of the tile cursor: G = (g_dn tiles_y + g_dty) tiles_x + g_dtx
   int* done;
   int* abort;
@@ -2118,7 +2119,6 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.wbase = lo;
   P.wspan = (unsigned)span;
   P.n = n;
-  P.ipr = 0;
   P.g_dn = grid / T;
   P.g_dty = (grid % T) / tiles_x;
   P.g_dtx = (grid % T) % tiles_x;
