@@ -1024,3 +1024,106 @@ extern "C" int sr_lrelu_fwd_f32(const float* x, float* y, float slope, int64_t n
   SR_CHECK_LAUNCH("lrelu_fwd");
   return SR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ Gram matrices (style term)
+// PerceptualLoss._gram_mat (basicsr/losses/losses.py:342-356): G[n] = F[n] F[n]^T * scale, F = the NCHW feature map as [c, h*w].
+// Small matrices (c <= 512) over long rows (h*w up to 128^2): a 32x32 tile of G per workgroup, the pixel axis in chunks of 32
+// through the LDS (rows read along the contiguous pixel axis), 2x2 outputs per thread, fp32 FMA in pixel order — the result does not
+// depend on the launch geometry.  Backward: dF = (dG + dG^T) F * scale, a 32 (channels) x 64 (pixels) tile per workgroup.
+namespace {
+__global__ __launch_bounds__(256) void gram_fwd_kernel(const float* __restrict__ f, float* __restrict__ g, int c, long long hw, float scale) {
+  __shared__ float a[32][33], b[32][33];
+  const int n = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const float* fn = f + (size_t)n * c * hw;
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // loader: row of the tile, first of 4 pixels
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (long long p0 = 0; p0 < hw; p0 += 32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long p = p0 + lc + e;
+      a[lr][lc + e] = (i0 + lr < c && p < hw) ? fn[(size_t)(i0 + lr) * hw + p] : 0.f;
+      b[lr][lc + e] = (j0 + lr < c && p < hw) ? fn[(size_t)(j0 + lr) * hw + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float a0 = a[2 * ti][k], a1 = a[2 * ti + 1][k], b0 = b[2 * tj][k], b1 = b[2 * tj + 1][k];
+      acc[0][0] += a0 * b0;
+      acc[0][1] += a0 * b1;
+      acc[1][0] += a1 * b0;
+      acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = i0 + 2 * ti + u, j = j0 + 2 * tj + v;
+      if (i < c && j < c) g[((size_t)n * c + i) * c + j] = acc[u][v] * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ f, const float* __restrict__ dg, float* __restrict__ df, int c,
+                                                       long long hw, float scale) {
+  __shared__ float s[32][33], x[32][65];
+  const int n = blockIdx.z, i0 = blockIdx.y * 32;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const float* fn = f + (size_t)n * c * hw;
+  const float* dgn = dg + (size_t)n * c * c;
+  const int tid = threadIdx.x, ti = tid >> 4, tp = tid & 15;  // outputs: channels 2 ti, 2 ti + 1; pixels tp + 16 q, q = 0..3
+  float acc[2][4] = {};
+  for (int j0 = 0; j0 < c; j0 += 32) {
+    {
+      const int r = tid >> 3, cc = (tid & 7) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + r, j = j0 + cc + e;
+        s[r][cc + e] = (i < c && j < c) ? dgn[(size_t)i * c + j] + dgn[(size_t)j * c + i] : 0.f;
+      }
+      const int xr = tid >> 3, xc = (tid & 7) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const long long p = p0 + xc + e;
+        x[xr][xc + e] = (j0 + xr < c && p < hw) ? fn[(size_t)(j0 + xr) * hw + p] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float s0 = s[2 * ti][k], s1 = s[2 * ti + 1][k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xv = x[k][tp + 16 * q];
+        acc[0][q] += s0 * xv;
+        acc[1][q] += s1 * xv;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + 2 * ti + u;
+      const long long p = p0 + tp + 16 * q;
+      if (i < c && p < hw) df[((size_t)n * c + i) * hw + p] = acc[u][q] * scale;
+    }
+}
+}  // namespace
+
+extern "C" int sr_gram_fwd_f32(const float* feat, int n, int c, int64_t hw, float scale, float* gram, void* stream) {
+  SR_CHECK_ARG(feat && gram && n > 0 && c > 0 && hw > 0 && n < 65536, "sr_gram_fwd_f32: bad argument");
+  hipLaunchKernelGGL(gram_fwd_kernel, dim3((c + 31) / 32, (c + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, feat, gram, c, (long long)hw, scale);
+  SR_CHECK_LAUNCH("gram_fwd");
+  return SR_OK;
+}
+
+extern "C" int sr_gram_bwd_f32(const float* feat, const float* dgram, int n, int c, int64_t hw, float scale, float* dfeat, void* stream) {
+  SR_CHECK_ARG(feat && dgram && dfeat && n > 0 && c > 0 && hw > 0 && n < 65536 && (hw + 63) / 64 < (1ll << 31), "sr_gram_bwd_f32: bad argument");
+  hipLaunchKernelGGL(gram_bwd_kernel, dim3((unsigned)((hw + 63) / 64), (c + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, feat, dgram, dfeat, c,
+                     (long long)hw, scale);
+  SR_CHECK_LAUNCH("gram_bwd");
+  return SR_OK;
+}

@@ -223,6 +223,35 @@ class L1LossFn(torch.autograd.Function):
         return dp, None, None
 
 
+class GramFn(torch.autograd.Function):
+    """[n, c, h, w] -> [n, c, c] = F F^T / (c h w), F = the feature map as [c, h w] (PerceptualLoss._gram_mat, losses.py:342-356):
+    sr_gram_fwd_f32 / sr_gram_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        dev = x.device
+        g = torch.empty((n, c, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_gram_fwd_f32(x.data_ptr(), n, c, h * w, 1.0 / (c * h * w), g.data_ptr(), _stream(dev)), 'sr_gram_fwd_f32')
+        ctx.save_for_backward(x)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        lib = _lib.load()
+        x, = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_gram_bwd_f32(x.data_ptr(), dg.contiguous().float().data_ptr(), n, c, h * w, 1.0 / (c * h * w), dx.data_ptr(),
+                                           _stream(dev)), 'sr_gram_bwd_f32')
+        return dx
+
+
 class PixelLossFn(torch.autograd.Function):
     """weight * mean(criterion(pred - target)), criterion kind 1 = squared error, 2 = Charbonnier(eps)
     (sr_pixel_loss_fwd_f32 / sr_pixel_loss_bwd_f32)."""

@@ -3,14 +3,15 @@
 Counterpart of basicsr/losses/losses.py:249-356 with the reference's constructor: ``PerceptualLoss(layer_weights,
 vgg_type='vgg19', use_input_norm=True, range_norm=False, perceptual_weight=1.0, style_weight=0., criterion='l1')``;
 ``forward(x, gt) -> (percep_loss | None, style_loss | None)``.  Features come from archs/vgg_arch.py (HIP convolutions and
-pooling), the 'l1' criterion is the HIP L1 reduction.  The Gram matrices of the style term are a plain batched GEMM
-(``torch.bmm`` = rocBLAS) over the NCHW features and the 'fro' criterion is ``torch.linalg.norm`` of the difference, both
-under torch autograd on top of the HIP feature extractor.  'l2' raises AttributeError in the reference itself
+pooling), the 'l1' criterion is the HIP L1 reduction.  The Gram matrices of the style term are HIP kernels too
+(``hip_autograd.GramFn``: sr_gram_fwd_f32 / sr_gram_bwd_f32) and the 'fro' criterion is the square root of the fused
+squared-error reduction (``PixelLossFn``).  'l2' raises AttributeError in the reference itself
 (torch.nn.L2loss does not exist, losses.py:290) and NotImplementedError here."""
 import torch
 from torch import nn
 
 from ..archs.vgg_arch import VGGFeatureExtractor
+from ..hip_autograd import GramFn, PixelLossFn
 from ..utils.registry import LOSS_REGISTRY
 from .losses import L1Loss
 
@@ -35,16 +36,14 @@ class PerceptualLoss(nn.Module):
             raise NotImplementedError(f'{criterion} criterion has not been supported.')
 
     def _distance(self, a, b):
-        if self.criterion_type == 'fro':
-            return torch.linalg.norm((a - b).flatten())
+        if self.criterion_type == 'fro':  # ||a - b||_F = sqrt(numel * mean((a - b)^2))
+            return torch.sqrt(PixelLossFn.apply(a.contiguous(), b.contiguous(), float(a.numel()), 1, 0.0))
         return self.criterion(a.contiguous(), b.contiguous())
 
     @staticmethod
     def _gram_mat(x):
         """[n, c, h, w] -> [n, c, c] = F F^T / (c h w) (losses.py:342-356)."""
-        n, c, h, w = x.size()
-        features = x.reshape(n, c, h * w)
-        return features.bmm(features.transpose(1, 2)) / (c * h * w)
+        return GramFn.apply(x)
 
     def forward(self, x, gt):
         x_features = self.vgg(x)

@@ -261,6 +261,12 @@ int sr_patch_augment_u8_f32(const uint8_t* src, int64_t src_img_stride, int src_
                             const int32_t* left, int origin_mul, const int32_t* sym, float* dst, int n, int patch_h, int patch_w,
                             int swap_rb, const float* host_mean3, const float* host_std3, void* stream);
 
+/* Gram matrices of the style term (PerceptualLoss._gram_mat, basicsr/losses/losses.py:342-356): gram[n] = F[n] F[n]^T * scale with
+ * F[n] = the NCHW fp32 feature map as [c, hw] (scale = 1 / (c h w) in the reference), and the gradient dfeat = (dgram + dgram^T) F *
+ * scale.  fp32 FMA in pixel order (deterministic). */
+int sr_gram_fwd_f32(const float* feat, int n, int c, int64_t hw, float scale, float* gram, void* stream);
+int sr_gram_bwd_f32(const float* feat, const float* dgram, int n, int c, int64_t hw, float scale, float* dfeat, void* stream);
+
 /* Validation PSNR numerator (psnr_ssim.py:8-46 on tensor2img outputs, img_util.py:38-94): per image n,
  * sse[n] = sum over channels and the border-cropped region of (round(clamp(a,0,1)*255) - round(clamp(b,0,1)*255))^2,
  * a, b NCHW float in [0,1].  ws >= n*64 floats. */

@@ -175,3 +175,22 @@ def test_esrgan_step_with_perceptual_loss(cuda):
         log = model.get_current_log()
         assert 'l_g_percep' in log and all(np.isfinite(v) for v in log.values()), log
     assert all(p.grad is None for p in model.cri_perceptual.parameters())  # the VGG is frozen
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 48, 64), (1, 512, 6, 8), (3, 100, 17, 13), (2, 256, 32, 32)])
+def test_gram_matrix_kernels_against_float64(cuda, n, c, h, w):
+    """sr_gram_fwd_f32 / sr_gram_bwd_f32 (hip_autograd.GramFn = PerceptualLoss._gram_mat, losses.py:342-356) against a float64 batched
+    matrix product, values and gradient (fp32 accumulation over h*w terms: 1e-5 relative)."""
+    from image_restoration_amd.hip_autograd import GramFn
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g)
+    wgt = torch.randn(n, c, c, generator=g)
+    xc = x.to(cuda).requires_grad_(True)
+    got = GramFn.apply(xc)
+    (got * wgt.to(cuda)).sum().backward()
+    xr = x.double().requires_grad_(True)
+    f = xr.reshape(n, c, h * w)
+    ref = f.bmm(f.transpose(1, 2)) / (c * h * w)
+    (ref * wgt.double()).sum().backward()
+    assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert float((xc.grad.cpu().double() - xr.grad).norm() / xr.grad.norm()) < 1e-5
