@@ -196,8 +196,9 @@ int chain_check(const char* who) {
       w.host[i] = 0;
     }
   if (!hit) return SR_OK;
-  set_error("%s: an earlier dense-block launch timed out waiting for a neighbour tile (are all CUs of the GPU available to this "
-            "process?); its results were invalid", who);
+  set_error("%s: an earlier dense-block launch timed out waiting for a neighbour tile; its results were invalid.  The fused kernel "
+            "expects the workgroups of a launch to become resident together (one process per GPU); on a GPU shared with other "
+            "processes call sr_set_conv_chain(2): the chain launch makes no such assumption", who);
   return SR_ELAUNCH;
 }
 }  // namespace sr
