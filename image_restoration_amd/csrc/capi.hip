@@ -197,8 +197,8 @@ int chain_check(const char* who) {
     }
   if (!hit) return SR_OK;
   set_error("%s: an earlier dense-block launch timed out waiting for a neighbour tile; its results were invalid.  The fused kernel "
-            "expects the workgroups of a launch to become resident together (one process per GPU); on a GPU shared with other "
-            "processes call sr_set_conv_chain(2): the chain launch makes no such assumption", who);
+            "needs about six rows of 16x32 tiles resident at once; if the GPU cannot give this process that many CUs, call "
+            "sr_set_conv_chain(2): the chain launch has no such need", who);
   return SR_ELAUNCH;
 }
 }  // namespace sr

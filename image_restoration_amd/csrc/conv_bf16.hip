@@ -831,6 +831,9 @@ struct StepD {
   int pre;          // the operands of this step's first unit were read during the previous step
   int nx_tile;      // 1 / 2: the next round's x chunks 0-1 / 2-3 are issued after the step's barrier (their buffers are free)
   int nx_q0, nx_q1; // the next round's weight piece groups [nx_q0, nx_q1) are issued after the step's barrier
+  int Kclaim;       // claim == 2: thread 0's instructions younger than its ticket atomic
+  int claim;        // 1: the workgroup's next tile is claimed during this step (its last neighbour flags have been seen), 2: the
+                    // ticket is handed to all waves (through the LDS; readable behind the next barrier)
 };
 struct Sched {
   int nsteps, npieces, ngroups, q_init, q_ahead, ok;  // q_ahead: groups of the next round issued during a round (the rest, up to q_init, at its start)
@@ -950,8 +953,22 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
       if (s.st[j].tb == 2 || s.st[j].tb == 3) last23 = j;
     }
     if (last01 + 1 >= ns || last23 + 1 >= ns || last01 >= last23) s.ok = 0;
-    s.st[last01 + 1].nx_tile = 1;
-    s.st[last23 + 1].nx_tile = 2;
+    // the next tile is claimed once this one depends on nobody any more (the step that issues x4's tile has seen the last neighbour
+    // flags), the ticket reaches all waves a few steps later; its x chunks follow as soon as ticket and buffers are there
+    int claim_at = -1, hand_at = -1;
+    for (int j = 0; j < ns; ++j) {
+      if (s.st[j].tile_in == 4) claim_at = j;
+      if (s.st[j].first_of_in == 4) hand_at = j;
+    }
+    if (claim_at < 0 || hand_at - 3 < claim_at || hand_at + 2 >= ns) s.ok = 0;
+    claim_at = hand_at - 3;  // (not earlier than necessary: the ticket waits in a register of thread 0 until the hand-over)
+    s.st[claim_at].claim = 1;
+    s.st[hand_at].claim = 2;
+    const int n1 = last01 + 1 > hand_at + 1 ? last01 + 1 : hand_at + 1;
+    const int n2 = last23 + 1 > n1 + 1 ? last23 + 1 : n1 + 1;
+    if (n2 >= ns) s.ok = 0;
+    s.st[n1].nx_tile = 1;
+    s.st[n2].nx_tile = 2;
     const int total = s.ngroups * 8;
     int k = 0;
     for (int i = 0; i < ns && k < RING / 8; ++i) {
@@ -973,6 +990,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     s.q_ahead = k;
   }
   // the issue sequence of one wave: what is younger than the operations a step needs may stay in flight at its wait
+  int cseq = 0;
   int seq = 0, gend[MAXP / 8] = {}, tend[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, send[5] = {0, 0, 0, 0, 0}, fseq[5] = {0, 0, 0, 0, 0};
   seq += 5;  // chunks 0-1 of x: 40 pieces = 5 per wave
   tend[0][0] = seq;
@@ -999,6 +1017,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
       if (send[d.publish] > need) need = send[d.publish];
     }
     d.K = seq - need;
+    if (d.claim == 2) d.Kclaim = seq - cseq;  // (handed over before this step issues anything)
     if (d.tile_in) {
       d.Kflag = seq - fseq[d.tile_in];
       seq += 5;  // two chunks: 40 pieces
@@ -1014,12 +1033,13 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     seq += d.nx_q1 - d.nx_q0;
     if (mode && d.first_of_in == 4) seq += 16;  // lean kernels: conv5's residual sources are fetched here
     if (mode == 2 && mask_conv_at(s, i)) seq += 4;  // ... and conv k's mask kMaskLead steps before its epilogue
+    if (d.claim == 1) cseq = seq;  // thread 0 only: the ticket atomic, behind everything this step issues
     if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
     if (d.post >= 1 && d.post <= 4) {
       seq += 4;  // the epilogue's stores: 2 rows x 2 channel blocks
       send[d.post] = seq;
     }
-    if (d.K > 60 || d.Kflag > 60) s.ok = 0;
+    if (d.K > 60 || d.Kflag > 60 || d.Kclaim > 60) s.ok = 0;
   }
   if (issued != s.ngroups) s.ok = 0;
   return s;
@@ -1030,6 +1050,8 @@ template <int MODE, int S>
 constexpr int step_K() { return MODE == 0 ? kS.st[S].K : MODE == 1 ? kSL.st[S].K : kSB.st[S].K; }
 template <int MODE, int S>
 constexpr int step_Kflag() { return MODE == 0 ? kS.st[S].Kflag : MODE == 1 ? kSL.st[S].Kflag : kSB.st[S].Kflag; }
+template <int MODE, int S>
+constexpr int step_Kclaim() { return MODE == 0 ? kS.st[S].Kclaim : MODE == 1 ? kSL.st[S].Kclaim : kSB.st[S].Kclaim; }
 struct WTab {
   unsigned v[MAXP];
 };
@@ -1046,7 +1068,7 @@ struct FusedParams {
   const char* wbase;
   unsigned wspan;      // bytes covered by the five images from wbase
   int n, tiles_x, tiles_y;       // images, tile grid of an image
-  int g_dn, g_dty, g_dtx;        // the grid size G as a step of the tile cursor: G = (g_dn tiles_y + g_dty) tiles_x + g_dtx
+  int* head;                     // ticket counter of this launch (zero before it): tiles are claimed in image-major, row-major order
   int* done;
   int* abort;
   int epoch;
@@ -1083,6 +1105,9 @@ struct Env {
   lds_int_p ctl;       // LDS word: a dependency wait timed out
   int wave, tid;
   int n, tile, x0, y0;  // image, tile of the batch, first column / row of the tile
+  int next;             // the workgroup's next tile (ticket), known from the hand-over step on
+  unsigned claimed;     // thread 0: the ticket as the atomic returns it
+  lds_int_p nextp;      // LDS word through which thread 0 hands the ticket to the other waves
   unsigned xpk[5];     // per tile piece of this wave: pixel row | column << 8 | swizzle bit << 16 | inside the tile << 17
   unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
   unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
@@ -1114,21 +1139,6 @@ __device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buf
     __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, vo,
                                              (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
   }
-}
-
-// The tile G positions behind (n, ty, tx) in image-major, row-major order — additions and two carries instead of two divisions.
-__device__ __forceinline__ void tile_step(const FusedParams& P, int& n, int& ty, int& tx) {
-  tx += P.g_dtx;
-  if (tx >= P.tiles_x) {
-    tx -= P.tiles_x;
-    ++ty;
-  }
-  ty += P.g_dty;
-  if (ty >= P.tiles_y) {
-    ty -= P.tiles_y;
-    ++n;
-  }
-  n += P.g_dn;
 }
 
 template <int Q>
@@ -1414,6 +1424,7 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   }
   wait_vm<step_K<MODE, S>()>();
   __builtin_amdgcn_s_barrier();
+  if constexpr (S > 0 && kS.st[S > 0 ? S - 1 : 0].claim == 2) e.next = __builtin_amdgcn_readfirstlane(*(volatile lds_int_p)e.nextp);
   if constexpr (S == 0) stamp(e, 1);
   if constexpr (d.tile_in > 0) stamp(e, 2 + 8 * (d.tile_in - 1) + 5);
   if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 7);
@@ -1428,17 +1439,23 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
   // read ahead), so its scalar / vector work — offset table reads, lane offsets of tile pieces, descriptors — sits in the matrix
   // pipe's shadow instead of between the barrier and the first MFMA.
   auto issue_all = [&]() {
+  if constexpr (d.claim == 2) {  // thread 0 hands its ticket to the other waves (they read it behind the next barrier)
+    if (e.tid == 0) {
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(e.claimed) : "n"(step_Kclaim<MODE, S>()) : "memory");
+      *(volatile lds_int_p)e.nextp = (int)e.claimed;
+    }
+  }
   if constexpr (d.tile_in > 0)
     issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in), e.x0, e.y0);  // agent scope: written by other workgroups of this launch
   issue_wgroups<d.q0, d.q1>(e, w_rs);
   if constexpr (d.nx_tile > 0) {  // the workgroup's next tile (behind the last one: an empty descriptor = zeros, no traffic)
-    int nn = e.n, tyn = e.y0 / TH, txn = e.x0 >> 5;
-    tile_step(P, nn, tyn, txn);
-    const bool more = nn < P.n;
+    const int T = P.tiles_x * P.tiles_y;
+    const bool more = e.next < P.n * T;
+    const int nn = more ? e.next / T : 0, tn = more ? e.next - nn * T : 0, tyn = tn / P.tiles_x;
     const char* in0 = kernarg_at<const char*>(offsetof(ConvParamsH, in));
     const long long nb0 = kernarg_at<long long>(offsetof(ConvParamsH, in_nb));
-    issue_tile_pair<0>(e, make_rsrc(in0 + (more ? nn : 0) * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
-                       txn * 32, tyn * TH);
+    issue_tile_pair<0>(e, make_rsrc(in0 + nn * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
+                       (tn - tyn * P.tiles_x) * 32, tyn * TH);
   }
   issue_wgroups<d.nx_q0, d.nx_q1>(e, w_rs);
   if constexpr (d.flag_in > 0) {
@@ -1463,6 +1480,15 @@ __device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, R
       __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
       fetch_mask(e, M, make_rsrc(mp + e.n * nbm, 2u * e.plane_b));
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (d.claim == 1) {
+    // The ticket of the workgroup's next tile: a returning atomic by thread 0, as inline asm so that nothing waits for it here (a
+    // builtin atomic is followed by vmcnt(0) at once: ~4 thousand cycles behind this step's agent-scope tile loads, and the whole
+    // workgroup behind that at the next barrier).  Its value is consumed three steps later behind a counted wait.
+    if (e.tid == 0) {
+      unsigned zero = 0u, one = 1u;
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(e.claimed) : "v"(zero), "v"(one), "s"(P.head) : "memory");
     }
   }
   };
@@ -1574,21 +1600,26 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     e.dbg[60] = __builtin_readcyclecounter();
     e.dbg[62] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
   }
-  int cn = 0, cty = 0, ctx = 0;  // this workgroup's tile: image, tile row, tile column (the first one: two divisions, then tile_step)
-  {
-    const int b = blockIdx.x;
-    cn = b / T;
-    const int t = b - cn * T;
-    cty = t / P.tiles_x;
-    ctx = t - cty * P.tiles_x;
-  }
+  // Tiles are claimed from a counter, in image-major, row-major order over the whole batch, and a workgroup claims its next tile only
+  // when the current one depends on nobody any more.  The tiles in flight are then a window of that order as wide as the number of
+  // RESIDENT workgroups, whatever that number is: a tile's dependencies (its 8 neighbours, at most one tile row ahead, per conv)
+  // are running or finished as long as ~5 rows of tiles fit the window (the host asks for 6 tiles_x + 2 <= grid).
+  __shared__ int s_next;
+  e.nextp = (lds_int_p)&s_next;
+  e.claimed = 0u;
+  if (e.tid == 0) s_next = atomicAdd(P.head, 1);
+  __syncthreads();  // also: s_ctl, the biases and the weight-offset table are set
+  int cur = s_next;
+  const int NT = P.n * T;
   for (int round = 0;; ++round) {
-    if (cn >= P.n) break;
-    e.n = cn;
-    const int ty = cty, tx = ctx;
+    if (cur >= NT) break;
+    e.n = cur / T;
+    const int t = cur - e.n * T;
+    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
     e.x0 = tx * 32;
     e.y0 = ty * TH;
-    e.tile = (cn * P.tiles_y + ty) * P.tiles_x + tx;
+    e.tile = cur;
+    e.next = NT;
     {  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
       int nb = -1;
       if (e.wave == 0 && lane < 9) {
@@ -1602,7 +1633,6 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     // (the x chunks and the first weight groups of the next tile are issued during this one — make_sched: nx_tile, nx_q* —, the same
     // instructions in the same order before the first tile)
     if (round == 0) {
-      __syncthreads();  // s_ctl, the biases and the weight-offset table are set
       issue_tile_pair<0>(e, x_rs, 0, 0, e.x0, e.y0);
       issue_tile_pair<0>(e, x_rs, 2, 2, e.x0, e.y0);
       issue_wgroups<0, kS.q_ahead>(e, w_rs);
@@ -1615,7 +1645,7 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     MaskRegs M;
     if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) break;
     stamp(e, 42);
-    tile_step(P, cn, cty, ctx);
+    cur = e.next;
   }
   if (e.dbg && e.tid == 0) e.dbg[61] = __builtin_readcyclecounter();  // ... and end
   fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
@@ -2119,9 +2149,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   P.wbase = lo;
   P.wspan = (unsigned)span;
   P.n = n;
-  P.g_dn = grid / T;
-  P.g_dty = (grid % T) / tiles_x;
-  P.g_dtx = (grid % T) % tiles_x;
+  P.head = sync + 1 + call_index;
   P.tiles_x = tiles_x;
   P.tiles_y = tiles_y;
   P.abort = sync;

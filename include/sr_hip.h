@@ -229,8 +229,8 @@ int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
  * tiles on two workgroups per CU, 3 (default) = the fused dense-block kernel where the five descriptors are one 64 + 4 x 32
  * channel block over a single concat buffer (a dense block, forward or transposed) and six rows of 16x32 tiles fit the CUs the
  * launch may use — one workgroup per tile keeps the partial sums of all unfinished convs in registers, every input is staged
- * once, images may have more tiles than the chip has CUs — and mode 2 otherwise.  Mode 3 expects the workgroups of a launch to
- * become resident together (one process per GPU); on a GPU shared between processes use mode 2 (see sr_chain_watchdog).
+ * once, images may have more tiles than the chip has CUs (tiles are claimed in dependency order; about six tile rows must be
+ * resident) — and mode 2 otherwise.
  *   sync        device int32[sr_conv3x3_chain_sync_ints(n, h, w)], zeroed by the caller (hipMemsetAsync) before the first call that
  *               uses it; calls sharing a block pass increasing call_index 0, 1, 2, ... < 256 and the same n / h / w
  *   sync[0]     is raised by the kernel if a wait on a dependency timed out (bounded spins: never a hang) */
