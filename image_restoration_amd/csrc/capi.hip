@@ -163,16 +163,20 @@ SideStreams& side_streams() {  // one set per (thread, device): streams and even
 // time-out — a GPU shared with another process, CUs withheld from this one — surfaces as an error on the next call instead of as
 // silently wrong images.  sr_chain_watchdog() reports and clears it at any time (after a synchronisation: for the work before it).
 namespace {
+// One watch per DEVICE for the whole process (mutex-guarded): autograd runs the backward drivers on its own thread, and a word those
+// queue must be seen by sr_chain_watchdog() on the caller's thread.
 struct Watch {
   int32_t* host = nullptr;  // kSlots pinned words
   int next = 0;
-  static constexpr int kSlots = 64;
+  bool sticky = false;  // a raised word that was about to be overwritten before anybody looked
+  static constexpr int kSlots = 256;
 };
-Watch& watch_of_device() {
-  thread_local std::map<int, Watch> per_device;
+std::mutex g_watch_mu;
+std::map<int, Watch> g_watch;
+Watch& watch_of_device() {  // g_watch_mu held
   int dev = 0;
   (void)hipGetDevice(&dev);
-  Watch& w = per_device[dev];
+  Watch& w = g_watch[dev];
   if (!w.host && hipHostMalloc((void**)&w.host, Watch::kSlots * sizeof(int32_t), hipHostMallocDefault) == hipSuccess)
     for (int i = 0; i < Watch::kSlots; ++i) w.host[i] = 0;
   return w;
@@ -180,16 +184,23 @@ Watch& watch_of_device() {
 }  // namespace
 namespace sr {
 void chain_watch(const int32_t* abort_word, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_watch_mu);
   Watch& w = watch_of_device();
   if (!w.host || !abort_word) return;
   const int slot = w.next;
   w.next = (w.next + 1) % Watch::kSlots;
+  if (((volatile int32_t*)w.host)[slot] != 0) {  // kSlots copies ago and never checked: keep it
+    w.sticky = true;
+    w.host[slot] = 0;
+  }
   (void)hipMemcpyAsync(w.host + slot, abort_word, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
 }
 int chain_check(const char* who) {
+  std::lock_guard<std::mutex> lk(g_watch_mu);
   Watch& w = watch_of_device();
   if (!w.host) return SR_OK;
-  bool hit = false;
+  bool hit = w.sticky;
+  w.sticky = false;
   for (int i = 0; i < Watch::kSlots; ++i)
     if (((volatile int32_t*)w.host)[i] != 0) {
       hit = true;

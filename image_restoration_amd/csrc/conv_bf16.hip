@@ -1336,11 +1336,6 @@ __global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedP
     const float* b = P.lv[k].bias;
     ((float*)(smem + LDS_BIAS))[e.tid] = (b && i < (k < 4 ? 32 : 64)) ? b[i] : 0.f;
   }
-  // Tiles of the whole batch in image-major, row-major order; workgroup b takes tiles b, b + G, b + 2G, ... (G = grid).  Every
-  // workgroup walks its tiles in increasing order, so the tiles in flight are always a window [m, m + G) of that order, m = the
-  // smallest unfinished tile: a tile's dependencies (its 8 neighbours, at most one row of tiles ahead, per conv) are then running or
-  // finished as long as the window holds the ~5 rows a block's hand-offs can keep blocked (the host checks G >= 6 tiles_x + 2) —
-  // no other co-residency is assumed, images may have more tiles than the chip has CUs.
   const int T = P.tiles_x * P.tiles_y;
   if (e.dbg && e.tid == 0) {  // absolute clocks (comparable inside an XCD) of this workgroup's start ...
     e.dbg[60] = __builtin_readcyclecounter();
@@ -1831,6 +1826,12 @@ extern "C" int sr_set_conv_chain(int enabled) {
 static long long* g_fused_clocks = nullptr;
 // Development aid (tools/fused_phase.py; not part of the ABI): 32 cycle stamps per workgroup of the fused dense-block kernel.
 extern "C" void sr_dev_fused_phase_clocks(void* buf) { g_fused_clocks = (long long*)buf; }
+// Development hook (tests/test_watchdog_gpu.py; not part of the ABI): launch the fused dense block with at most `cap` workgroups even
+// when that is fewer than the window of tile rows its hand-offs need — the launch then cannot make progress, every bounded wait spins
+// out, the abort word is raised and the give-up path (ctl word -> return false -> drain) runs: what a GPU that withholds CUs from this
+// process would cause, made deterministic.  0 = off.
+static int g_fused_grid_cap = 0;
+extern "C" void sr_dev_fused_grid_cap(int cap) { g_fused_grid_cap = cap; }
 
 // The dense block as rdb_fused_bf16_kernel when the five descriptors are one (64 + 4 x 32 channel) block over a single concat buffer and
 // every image's tiles fit the chip together; *launched says whether it ran.
@@ -1873,8 +1874,9 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   const int T = tiles_x * tiles_y;
   // the tiles in flight are a window of the row-major tile order (see the kernel): it must hold the rows a block's hand-offs can block
   const long long NT = (long long)T * n;
-  const int grid = (int)(NT < avail ? NT : avail);
+  int grid = (int)(NT < avail ? NT : avail);
   if (grid < NT && grid < 6 * tiles_x + 2) return SR_OK;
+  if (g_fused_grid_cap > 0 && grid > g_fused_grid_cap) grid = g_fused_grid_cap;
   if (NT >= (1ll << 30)) return SR_OK;
   fz::FusedParams P = {};
   const char* lo = (const char*)d[0].wpacked;
@@ -2106,7 +2108,9 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
           case 2: go(conv_stream_bf16_kernel<2, 1, false>, st::Cfg<2, 1, false>::LDS_BYTES); break;
           case 3: go(conv_stream_bf16_kernel<2, 1, true>, st::Cfg<2, 1, true>::LDS_BYTES); break;
           case 4: go(conv_stream_bf16_kernel<2, 2, false>, st::Cfg<2, 2, false>::LDS_BYTES); break;
-          case 5: go(conv_stream_bf16_kernel<2, 2, true>, st::Cfg<2, 2, true>::LDS_BYTES); break;
+          case 5:  // excluded above: at 2 chunks + an extra operand hipcc spills 176 VGPRs (tests/test_codeobj_host.py), so it is not built
+            sr::set_error("sr_conv3x3_bf16: internal dispatch error (streaming conv, 2 chunks + extra operand)");
+            return SR_EINVAL;
           case 6: go(conv_stream_bf16_kernel<2, 3, false>, st::Cfg<2, 3, false>::LDS_BYTES); break;
           case 7: go(conv_stream_bf16_kernel<2, 3, true>, st::Cfg<2, 3, true>::LDS_BYTES); break;
           case 8: go(conv_stream_bf16_kernel<2, 4, false>, st::Cfg<2, 4, false>::LDS_BYTES); break;

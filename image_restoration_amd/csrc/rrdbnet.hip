@@ -314,6 +314,8 @@ int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x,
                P.unshuffle);
   SR_CHECK_ARG((uintptr_t)workspace % 256 == 0, "sr_rrdbnet_forward: workspace must be 256-byte aligned");
   const int h = h_in / P.unshuffle, w = w_in / P.unshuffle;
+  if (int rc = sr::chain_check("sr_rrdbnet_forward"))
+    return rc;  // a hand-off time-out of an earlier call (capi.hip; the fp32 chain launch is opt-in, sr_set_conv_chain_f32)
   const FwdSpace W = carve_fwd(cfg, P, n, h, w, (char*)workspace, train);
   if (W.bytes > workspace_bytes) {
     sr::set_error("sr_rrdbnet_forward: workspace %zu B < required %zu B", workspace_bytes, W.bytes);
@@ -332,14 +334,20 @@ int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x,
     sr::set_error("sr_rrdbnet_forward: sync memset failed");
     return SR_ELAUNCH;
   }
-  if (groups <= 1 || sr::prof_on()) return forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train, W.sync);
+  if (groups <= 1 || sr::prof_on()) {
+    const int rc = forward_body(cfg, P, W, packed, x, y, n, h, w, stream, train, W.sync);
+    sr::chain_watch(W.sync, stream);
+    return rc;
+  }
   const size_t in_img = (size_t)cfg->num_in_ch * h_in * w_in;
   const size_t out_img = (size_t)cfg->num_out_ch * (size_t)(h * 4) * (w * 4);
-  return sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
+  const int rc = sr::run_image_groups(n, groups, stream, [&](int g, int n0, int cnt, hipStream_t s) {
     const FwdSpace S = shift_space(cfg, P, W, n0, h, w);
     return forward_body(cfg, P, S, packed, x + n0 * in_img, y + n0 * out_img, cnt, h, w, s, train,
                         W.sync + (size_t)(g % kSyncBlocks) * W.sync_ints);
   });
+  for (int g = 0; g < groups && g < kSyncBlocks; ++g) sr::chain_watch(W.sync + (size_t)g * W.sync_ints, stream);
+  return rc;
 }
 
 size_t space_bytes(const sr_rrdbnet_cfg* cfg, int n, int h, int w, int which) {

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .archs import build_network
+from . import watchdog
 from .tiling import tiled_forward
 from .utils.img_util import img2tensor, tensor2img
 
@@ -53,7 +54,7 @@ def restore(net, img_bgr_u8, tile=0, tile_pad=16, scale=4, rank=0, world_size=1)
         if tile and (max(x.shape[2:]) > tile or world_size > 1):
             y = tiled_forward(net, x, tile, tile_pad, scale, rank=rank, world_size=world_size)
         else:
-            y = net(x) if rank == 0 else None
+            y = watchdog.guarded(lambda: net(x), 'restore') if rank == 0 else None   # tiled_forward guards itself
     return None if y is None else tensor2img(y, rgb2bgr=True, min_max=(0, 1))
 
 

@@ -65,6 +65,14 @@ class BaseModel:
         self.device = torch.device('cpu' if opt['num_gpu'] == 0 else 'cuda')
         self.distributed = bool(opt.get('dist'))
         self.logger = logging.getLogger('basicsr')
+        if not self.distributed and isinstance(opt['num_gpu'], int) and opt['num_gpu'] > 1:
+            # the reference falls back to single-process nn.DataParallel here (base_model.py:74-75); this build scales only as
+            # one process per GPU, so say what happens instead of silently using one device
+            self.logger.warning(
+                f"num_gpu = {opt['num_gpu']} without a launcher: there is no single-process DataParallel on this path, the job "
+                f"runs on cuda:{torch.cuda.current_device() if torch.cuda.is_available() else 0} only.  For {opt['num_gpu']} GPUs "
+                f"start it as `python -m torch.distributed.run --nproc-per-node {opt['num_gpu']} --master-addr 127.0.0.1 -m "
+                'image_restoration_amd.train -opt <yml> --launcher pytorch`.')
         self.packs = OrderedDict()   # label ('g', 'd') -> NetPack
         self.schedulers = []
         self.log_dict = OrderedDict()

@@ -11,6 +11,7 @@ from collections import OrderedDict
 
 import torch
 
+from .. import watchdog
 from ..archs import build_network
 from ..losses import build_loss
 from ..utils.registry import MODEL_REGISTRY
@@ -101,7 +102,9 @@ class SRModel(BaseModel):
                 book.charge(pre + 'style', style)
 
     def finish_step(self, book):
-        self.log_dict = self.reduce_loss_dict(book.entries)
+        self.log_dict = self.reduce_loss_dict(book.entries)   # .tolist(): the step's launches have finished
+        if self.device.type == 'cuda':
+            watchdog.verify('optimize_parameters', synchronize=False)   # invalid gradients must not pass as a step
         if self.ema_decay > 0:
             self.gen.blend_shadow(self.ema_decay)
 
@@ -124,7 +127,10 @@ class SRModel(BaseModel):
             runner = self.net_g
         runner.eval()
         with torch.no_grad():
-            self.output = runner(self.lq)
+            if self.lq.is_cuda:   # the image goes to metrics / a PNG next: never hand over a timed-out forward
+                self.output = watchdog.guarded(lambda: runner(self.lq), 'SRModel.test')
+            else:
+                self.output = runner(self.lq)
         if restore:
             self.net_g.train()
 
@@ -197,6 +203,8 @@ class SRModel(BaseModel):
     # ------------------------------------------------------------------ files
     def save(self, epoch, current_iter):
         """net_g_<iter>.pth holds ``params`` (+ ``params_ema`` when the shadow exists), then the training state."""
+        if self.device.type == 'cuda':
+            watchdog.verify('save')   # never write a checkpoint behind a step that timed out
         if self.gen.shadow is not None:
             self.save_network([self.net_g, self.gen.shadow], 'net_g', current_iter, param_key=['params', 'params_ema'])
         else:

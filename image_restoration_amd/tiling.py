@@ -11,6 +11,8 @@ rank by one device-side gather (the path's only exchange step).
 """
 import torch
 
+from . import watchdog
+
 
 def plan_tiles(h, w, tile, pad):
     """List of cells: (y0, y1, x0, x1) of the cell and (py0, py1, px0, px1) of its padded window, LR coordinates."""
@@ -90,7 +92,12 @@ def tiled_forward(net, img, tile=512, pad=16, scale=4, max_batch=8, rank=0, worl
     h, w = img.shape[2:]
     cells = list(enumerate(plan_tiles(h, w, tile, pad)))
     mine = [c for c in cells if c[0] % world_size == rank]
-    crops = _run_cells(net, img, mine, scale, max_batch)
+    # the crops are about to leave the device (gather, uint8 copy, the caller's imwrite): a dense-block launch that timed out
+    # must not hand over invalid pixels (watchdog.py; the cells are repeated on the chain launch in this process)
+    if img.is_cuda:
+        crops = watchdog.guarded(lambda: _run_cells(net, img, mine, scale, max_batch), 'tiled_forward')
+    else:
+        crops = _run_cells(net, img, mine, scale, max_batch)
     if out_dtype == torch.uint8:
         crops = {i: quantise_u8(c) for i, c in crops.items()}
     n_out = next(iter(crops.values())).size(1) if crops else getattr(net, 'num_out_ch', img.size(1))

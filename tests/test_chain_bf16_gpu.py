@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def chain_restore():
-    """Both tile geometries of the chain launch (sr_set_conv_chain 1: 32-row ring tiles, 2: 16-row tiles, the default)."""
+    """Both tile geometries of the chain launch (sr_set_conv_chain 1: 32-row ring tiles, 2: 16-row tiles) and the fused kernel (3, the
+    library's default, restored afterwards so that the tests that follow in the same process run what the product runs)."""
     yield
-    _lib.check(_lib.load().sr_set_conv_chain(2), 'sr_set_conv_chain')
+    _lib.check(_lib.load().sr_set_conv_chain(3), 'sr_set_conv_chain')
 
 
 def _rdb(dev, nf, gc, seed):

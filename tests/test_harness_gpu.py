@@ -303,3 +303,30 @@ def test_bench_line_contract(cuda):
     for key in ('c5_tiled_4k_bf16', 'c5_tiled_4k_fp32'):
         assert sec[key]['unit'] == 'frames/sec' and sec[key]['scaling'] == 'strong' and sec[key]['value'] > 0.1
     check_roofline(sec['c5_tiled_4k_bf16']['roofline'])
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_tiled_forward_at_the_4k_cell_size_equals_the_untiled_forward_of_every_padded_cell(cuda, dtype):
+    """BASELINE config 5's geometry (512 x 512 LR cells + 16 px pad, 23 blocks, nf 64) on a 1024 x 1024 frame: each assembled
+    2048 x 2048 HR crop equals, bit for bit, the centre of the un-tiled forward of its own padded cell run alone (the
+    paste rule; G-k pins the rule at tile 16 against the reference, this pins the product at the size it is benchmarked at — the
+    batched cells go through the fused dense-block kernel as a sliding window of 544 tiles per image in bf16)."""
+    from image_restoration_amd import watchdog
+    from image_restoration_amd.tiling import plan_tiles
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32)
+    net = ira.build_network(dict(type='RRDBNet', compute_dtype=dtype, **cfg)).to(cuda).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(0, **cfg).items()}, strict=True)
+    img = torch.from_numpy(synth.uniform_input(21, (1, 3, 1024, 1024))).to(cuda)
+    before = watchdog.fallback_count
+    out = tiled_forward(net, img, tile=512, pad=16, scale=4)
+    assert out.shape == (1, 3, 4096, 4096) and watchdog.fallback_count == before
+    cells = plan_tiles(1024, 1024, 512, 16)
+    assert len(cells) == 4
+    with torch.no_grad():
+        for (y0, y1, x0, x1), (py0, py1, px0, px1) in cells:
+            assert (py1 - py0, px1 - px0) == (528, 528)
+            alone = net(img[:, :, py0:py1, px0:px1].contiguous())
+            oy, ox = (y0 - py0) * 4, (x0 - px0) * 4
+            assert torch.equal(out[:, :, y0 * 4:y1 * 4, x0 * 4:x1 * 4], alone[:, :, oy:oy + 2048, ox:ox + 2048]), (y0, x0)
+    assert not watchdog.tripped()
+    assert torch.isfinite(out).all() and float(out.std()) > 0
