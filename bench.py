@@ -389,6 +389,7 @@ def main():
     ap.add_argument('--rows8', type=int, default=-1, help='tuning: fp32 32-cout convs on 16- (0), 8- (1) or 4-row (2) tiles (development switch)')
     ap.add_argument('--tall64', action='store_true', help='tuning: fp32 64-cout convs on 16-row tiles (development switch)')
     ap.add_argument('--stream', type=int, default=-1, help='tuning: 0 = large few-channel bf16 convs on the per-tile kernel instead of the streaming kernel (development switch)')
+    ap.add_argument('--overlap', type=int, default=-1, help='tuning: weight gradients of the backward drivers on a side stream: -1 automatic (small launches), 0 never, 1 always (development switch)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C3 training step and the C5 tiled frame next to the headline')
     ap.add_argument('--secondary-timeout', type=float, default=300.0)
     ap.add_argument('--profile', action='store_true', help='--mode train|tiled: add the roofline of the dominant kernel')
@@ -424,6 +425,9 @@ def main():
     if args.stream >= 0:
         from image_restoration_amd import _lib
         _lib.load().sr_dev_set_conv_stream(args.stream)
+    if args.overlap != -1:
+        from image_restoration_amd import _lib
+        _lib.load().sr_dev_set_backward_overlap(args.overlap)
     if args.chain:
         from image_restoration_amd import _lib
         _lib.check(_lib.load().sr_set_conv_chain(args.chain), 'sr_set_conv_chain')

@@ -217,6 +217,41 @@ extern "C" int sr_chain_watchdog(void) { return sr::chain_check("sr_chain_watchd
 // Development hook (tests): queue a copy of one device word the way the network drivers queue their abort words.
 extern "C" void sr_dev_chain_watch(const int32_t* word, void* stream) { sr::chain_watch(word, (hipStream_t)stream); }
 
+// ---- the weight-gradient lane of the backward drivers (sr_internal.h) ----
+namespace {
+int g_backward_overlap = -1;
+struct LaneEvents {
+  hipEvent_t handoff = nullptr, ring[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = false;
+};
+}  // namespace
+namespace sr {
+int backward_overlap() { return g_backward_overlap; }
+bool WgradLane::begin(hipStream_t caller, bool enable) {
+  main = side = caller;
+  on = false;
+  last = -1;
+  if (!enable || prof_on()) return false;  // (the launch profiler times launches on one stream)
+  SideStreams& S = side_streams();
+  if (!S.ensure()) return false;
+  thread_local std::map<int, LaneEvents> per_device;  // events belong to the device they were made on
+  LaneEvents& E = per_device[S.device];
+  if (!E.ok) {
+    if (hipEventCreateWithFlags(&E.handoff, hipEventDisableTiming) != hipSuccess) return false;
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&E.ring[i], hipEventDisableTiming) != hipSuccess) return false;
+    E.ok = true;
+  }
+  side = S.s[2];
+  handoff = E.handoff;
+  for (int i = 0; i < 4; ++i) ring[i] = E.ring[i];
+  on = true;
+  return true;
+}
+}  // namespace sr
+// Development switch (not part of the ABI): -1 = automatic, 0 = weight gradients on the caller's stream, 1 = always on the lane.
+extern "C" void sr_dev_set_backward_overlap(int mode) { g_backward_overlap = mode; }
+
 extern "C" int sr_set_forward_groups(int groups) {
   SR_CHECK_ARG(groups >= 0 && groups <= 4, "sr_set_forward_groups: 0 (automatic) or 1..4");
   g_forward_groups = groups;

@@ -523,11 +523,26 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
     d.mask_slope = 0.2f;
     return sr_conv3x3_f32(&d, stream);
   };
+  // Weight gradients go to the lane (sr_internal.h: a side stream on small launches, else the caller's stream): they depend on the
+  // data gradients issued so far and only the optimiser waits for them.  Every call is one ticket; the caller's stream waits for a
+  // ticket (lane.need) before it overwrites a buffer that job reads.  The slab is the lane's alone.
+  sr::WgradLane lane;
+  {
+    const int mode = sr::backward_overlap();
+    lane.begin(stream, mode > 0 || (mode < 0 && (long long)n * hw < 256ll * 16 * 32));
+  }
+  long long ticket = 0;
   auto wgrad = [&](int ci, const float* xsrc, long long x_ns, int ih, int iw, int ups, const float* dyp,
                    long long dy_ns, float scale) -> int {
     const ConvPlan& cp = P.convs[ci];
     float* dwp = host_dparams[2 * ci];
     float* dbp = host_dparams[2 * ci + 1];
+    hipStream_t ws = lane.hand();
+    struct Done {  // every exit marks the ticket (the numbering must not depend on frozen parameters)
+      sr::WgradLane& l;
+      long long k;
+      ~Done() { l.done(k); }
+    } mark{lane, ticket++};
     if (!dwp) return SR_OK;  // parameter does not need a gradient
     sr_conv3x3_wgrad_desc d = {};
     d.x = xsrc;
@@ -549,7 +564,7 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
     d.accumulate = accumulate;
     d.slab = B.slab;
     d.slab_bytes = B.slab_bytes;
-    return sr_conv3x3_wgrad_f32(&d, stream);
+    return sr_conv3x3_wgrad_f32(&d, ws);
   };
 
   const int i_first = 0, i_body = nconv - 5, i_up1 = nconv - 4, i_up2 = nconv - 3, i_hr = nconv - 2, i_last = nconv - 1;
@@ -565,6 +580,7 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
              0.f, 0, S.hr, feat_ns * 16, 0, nfb);  // a16 = dL/d(conv_hr pre-activation)
   if (rc) return rc;
   // conv_hr
+  const long long t_hr = ticket;
   rc = wgrad(i_hr, S.up2, feat_ns * 16, 4 * h, 4 * w, 0, B.a16, feat_ns * 16, 1.f);
   if (rc) return rc;
   rc = dgrad(i_hr, B.a16, feat_ns * 16, 4 * h, 4 * w, B.b16, feat_ns * 16, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0,
@@ -573,6 +589,7 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
   // conv_up2 reads up1 through the nearest x2 upsample (:117)
   rc = wgrad(i_up2, S.up1, feat_ns * 4, 2 * h, 2 * w, 1, B.b16, feat_ns * 16, 1.f);
   if (rc) return rc;
+  lane.need(t_hr);  // a16 is written again below: conv_hr's weight gradient has read it
   rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16, feat_ns * 16, 1.f, nullptr, 0, 0.f, nullptr, 0, 0.f, 0,
              nullptr, 0, 0, 0);  // a16 = dL/d(upsampled up1)
   if (rc) return rc;
@@ -628,6 +645,7 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
     d.mask_slope = 0.2f;
     return sr_conv3x3_f32(&d, stream);
   };
+  long long block_ticket[4] = {-1, -1, -1, -1};  // last lane job that reads B.g[i]
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const float* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
@@ -647,8 +665,10 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
         if (rc) return rc;
       }
       // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
+      lane.need(block_ticket[(gi + 1) & 3]);  // Dn was the D of the block three steps ago: its weight gradients have read it
       rc = step(q, 0, D, P.nfp + 4 * P.gcp, Dn, cfg->num_feat, D, sres, r == 0 ? d_rrdb : nullptr, 1.f, nullptr, 0);
       if (rc) return rc;
+      block_ticket[gi] = ticket - 1;
       gi = (gi + 1) & 3;
     }
   }

@@ -459,11 +459,26 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     d.mask_slope = 0.2f;
     return sr_conv3x3_bf16(&d, stream);
   };
+  // Weight gradients go to the lane (sr_internal.h: a side stream on small launches, else the caller's stream): they depend on the
+  // data gradients issued so far and only the optimiser waits for them.  Ticket numbers count the lane's jobs; the caller's stream
+  // waits for a ticket (lane.need) before it overwrites a buffer that job reads.  The slab is the lane's alone.
+  sr::WgradLane lane;
+  {
+    const int mode = sr::backward_overlap();
+    lane.begin(stream, mode > 0 || (mode < 0 && (long long)n * hw < 256ll * 16 * 32));
+  }
+  long long ticket = 0;
   auto wgrad = [&](int ci, const __bf16* xsrc, long long x_ns, int ih, int iw, int ups, const __bf16* dyp, long long dy_ns,
                    float scale) -> int {
     const ConvPlanH& cp = P.convs[ci];
     float* dwp = host_dparams[2 * ci];
     float* dbp = host_dparams[2 * ci + 1];
+    hipStream_t ws = lane.hand();
+    struct Done {  // every exit marks the ticket, also the one of a frozen parameter (the numbering must not depend on it)
+      sr::WgradLane& l;
+      long long k;
+      ~Done() { l.done(k); }
+    } mark{lane, ticket++};
     if (!dwp) return SR_OK;  // parameter does not need a gradient
     sr_conv3x3_wgrad_desc d = {};
     d.x = (const float*)xsrc;
@@ -485,7 +500,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     d.accumulate = accumulate;
     d.slab = B.slab;
     d.slab_bytes = B.slab_bytes;
-    return sr_conv3x3_wgrad_bf16(&d, stream);
+    return sr_conv3x3_wgrad_bf16(&d, ws);
   };
 
   const int i_first = 0, i_body = nconv - 5, i_up1 = nconv - 4, i_up2 = nconv - 3, i_hr = nconv - 2, i_last = nconv - 1;
@@ -498,6 +513,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   if (rc) return rc;
   rc = dgrad(i_last, B.dyl, dyl_ns, 4 * h, 4 * w, B.a16, feat_ns * 16, S.hr, feat_ns * 16, nfb);  // a16 = dL/d(conv_hr pre-act)
   if (rc) return rc;
+  const long long t_hr = ticket;
   rc = wgrad(i_hr, S.up2, feat_ns * 16, 4 * h, 4 * w, 0, B.a16, feat_ns * 16, 1.f);
   if (rc) return rc;
   rc = dgrad(i_hr, B.a16, feat_ns * 16, 4 * h, 4 * w, B.b16, feat_ns * 16, S.up2, feat_ns * 16, nfb);  // b16 = dL/d(conv_up2 pre-act)
@@ -505,6 +521,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   // conv_up2 reads up1 through the nearest x2 upsample (:117)
   rc = wgrad(i_up2, S.up1, feat_ns * 4, 2 * h, 2 * w, 1, B.b16, feat_ns * 16, 1.f);
   if (rc) return rc;
+  lane.need(t_hr);  // a16 is written again below: conv_hr's weight gradient has read it
   rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16, feat_ns * 16, nullptr, 0, 0);  // a16 = dL/d(upsampled up1)
   if (rc) return rc;
   rc = sr_upsample2x_bwd_bf16(B.a16, feat_ns * 16, B.a4, feat_ns * 4, S.up1, feat_ns * 4, 0.2f, n, nfb, 2 * h, 2 * w, stream);
@@ -558,6 +575,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     return SR_ELAUNCH;
   }
   int chain_call = 0;
+  long long block_ticket[4] = {-1, -1, -1, -1};  // lane job that reads B.g[i]
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const __bf16* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
@@ -565,6 +583,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       const __bf16* cat = S.cat[q];
       __bf16* D = B.g[gi];  // D[0:nf] = dL/d(block output)
       __bf16* Dn = B.g[(gi + 1) & 3];
+      lane.need(block_ticket[(gi + 1) & 3]);  // Dn was the D of the block three steps ago: its weight gradients have read it
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
       // The transposed dense block as one chain of five convs over D (sr_conv3x3_chain_bf16: one launch where the shape allows):
       //   dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k   for sl = 4..1, each appended to D, then
@@ -578,7 +597,9 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       if (rc) return rc;
       // all five weight gradients of the block in one launch (conv5: dY5 = s5 * D[0:nf]); D is complete and stays intact
       rc = sr::rdb_wgrad_bf16(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5,
-                              accumulate, B.slab, B.slab_bytes, stream);
+                              accumulate, B.slab, B.slab_bytes, lane.hand());
+      block_ticket[gi] = ticket;
+      lane.done(ticket++);
       if (rc) return rc;
       gi = (gi + 1) & 3;
     }
@@ -594,6 +615,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     rc = sr_cb16_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
     if (rc) return rc;
   }
+  lane.end();  // the caller's stream (the optimiser step comes next) waits for the last weight gradient
   sr::chain_watch(B.sync, stream);
   return SR_OK;
 }

@@ -96,6 +96,43 @@ int run_image_groups(int n, int groups, hipStream_t stream, Body body) {
   return rc;
 }
 
+// A second lane (side stream) for work of a driver call that nothing on the caller's stream waits for before the call's end: the
+// weight gradients of a backward pass, which depend on each block's data gradients but feed only the optimiser.  On small launches
+// (the reference recipe's 32x32 patches: 64-256 workgroups of a few microseconds each) the data-gradient chain and the weight
+// gradients then overlap instead of queueing behind one another.  Stream order replaces every host synchronisation:
+//   hand()   work issued so far on the caller's stream is a dependency of what the lane gets next; returns the lane's stream
+//   done(k)  marks the lane's progress as `ticket k` (a ring of 4 events)
+//   need(k)  the caller's stream waits for ticket k — before it overwrites a buffer the lane's work of ticket k reads
+//   end()    the caller's stream waits for everything the lane was given
+// Disabled (on = false) every call degenerates to the caller's stream and no events.
+struct WgradLane {
+  hipStream_t main = nullptr, side = nullptr;
+  hipEvent_t handoff = nullptr, ring[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool on = false;
+  long long last = -1;
+  bool begin(hipStream_t caller, bool enable);
+  hipStream_t hand() {
+    if (!on) return main;
+    (void)hipEventRecord(handoff, main);
+    (void)hipStreamWaitEvent(side, handoff, 0);
+    return side;
+  }
+  void done(long long k) {
+    if (!on) return;
+    (void)hipEventRecord(ring[k & 3], side);
+    last = k;
+  }
+  void need(long long k) {  // (a slot the ring has lapped holds a LATER ticket of the same stream: waiting for that one is safe)
+    if (on && k >= 0 && k <= last) (void)hipStreamWaitEvent(main, ring[k & 3], 0);
+  }
+  void end() {
+    if (on && last >= 0) (void)hipStreamWaitEvent(main, ring[last & 3], 0);
+    on = false;
+  }
+  ~WgradLane() { end(); }  // error returns included: the caller's stream never runs ahead of work the lane still holds
+};
+int backward_overlap();  // sr_dev_set_backward_overlap: -1 automatic (small launches only), 0 never, 1 always
+
 #define SR_CHECK_ARG(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

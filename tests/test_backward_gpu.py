@@ -204,3 +204,41 @@ def test_rrdb_forward_and_backward_vs_reference_golden(cuda, golden):
     assert _rel(named['body.0.rdb3.conv5.weight'].grad, g['grad_rdb3_conv5_weight']) < 1e-4
     assert _rel(named['body.0.rdb1.conv1.weight'].grad, g['grad_rdb1_conv1_weight']) < 1e-4
     assert _rel(named['body.0.rdb2.conv3.bias'].grad, g['grad_rdb2_conv3_bias']) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(4, 3, 32, 32), (2, 3, 48, 80), (1, 3, 16, 24)])
+def test_weight_gradients_on_the_side_lane_equal_the_single_stream_backward_bit_for_bit(cuda, dtype, shape):
+    """sr_rrdbnet_backward_*: on small launches the weight gradients run on a second stream beside the data-gradient chain
+    (csrc/sr_internal.h WgradLane; stream order through events, a ring of four gradient buffers).  Nothing about the arithmetic
+    changes — every reduction is ordered — so parameter gradients and dL/dx must equal the one-stream backward bit for bit; a
+    missing dependency (a buffer overwritten before its weight gradient read it) shows up as a difference.  Repeated to let the
+    two streams drift differently."""
+    import ctypes as C
+    from image_restoration_amd import _lib
+    lib = _lib.load()
+    lib.sr_dev_set_backward_overlap.argtypes = [C.c_int]
+    lib.sr_dev_set_backward_overlap.restype = None
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=4, num_grow_ch=32)
+    net = ira.build_network(dict(type='RRDBNet', compute_dtype=dtype, **cfg)).to(cuda).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(11, **cfg).items()}, strict=True)
+    x = torch.from_numpy(synth.uniform_input(3, shape)).to(cuda).requires_grad_(True)
+    r = torch.from_numpy(synth.signed_input(4, (shape[0], 3, 4 * shape[2], 4 * shape[3]))).to(cuda)
+
+    def grads(mode):
+        lib.sr_dev_set_backward_overlap(mode)
+        for p in net.parameters():
+            p.grad = None
+        x.grad = None
+        (net(x) * r).sum().backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    try:
+        want = grads(0)
+        for rep in range(3):
+            got = grads(1)
+            for i, (a, b) in enumerate(zip(want, got)):
+                assert torch.equal(a, b), (rep, i)
+        assert all(torch.equal(a, b) for a, b in zip(want, grads(-1)))
+    finally:
+        lib.sr_dev_set_backward_overlap(-1)

@@ -284,7 +284,8 @@ def test_esrgan_model_bf16_first_iteration_tracks_reference(golden):
                 assert abs(log[k] - l64[j]) <= 2e-2 * max(abs(l64[j]), 1e-3), (k, log[k], l64[j])
 
 
-@pytest.mark.parametrize('nf,gc,n,h,w', [(64, 32, 2, 24, 72), (64, 32, 8, 32, 64), (16, 8, 3, 17, 40), (48, 24, 2, 16, 16)])
+@pytest.mark.parametrize('nf,gc,n,h,w', [(64, 32, 2, 24, 72), (64, 32, 8, 32, 64), (16, 8, 3, 17, 40), (48, 24, 2, 16, 16), (64, 32, 3, 40, 100),
+                                         (64, 32, 1, 5, 7), (64, 32, 1, 1, 70), (64, 32, 32, 128, 128)])
 def test_rdb_wgrad_bf16_single_launch_matches_per_conv_launches(nf, gc, n, h, w):
     """sr_rdb_wgrad_bf16 (all five convs of a dense block, one launch) == five sr_conv3x3_wgrad_bf16 calls on the same
     buffers up to fp32 summation order (2e-5 of the largest gradient entry), including accumulate and the conv5 scale."""
