@@ -160,6 +160,8 @@ SIGNATURES = {
                                         C.c_int, C.c_void_p]),
     'sr_bilinear2x_bwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
+    'sr_bilinear2x_bwd_lrelu_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                               C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sr_bn_lrelu_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -100,8 +100,8 @@ class UNetDiscriminatorSN(nn.Module):
     def _forward_bf16(self, x):
         """Same network on CB16 bf16 activations.  Neighbouring layers share memory passes (hip_autograd_bf16.py): the
         encoder activations fork into (skip, pixel-unshuffled conv input) with one fused gradient pass, the first two skip
-        additions ride on the bilinear resampling, and conv8 / conv9 apply their producer's LeakyReLU derivative in the
-        data-gradient epilogue."""
+        additions ride on the bilinear resampling, the resampling's backward applies the LeakyReLU derivative of the conv
+        that fed it, and conv8 / conv9 apply their producer's LeakyReLU derivative in the data-gradient epilogue."""
         from .. import hip_autograd_bf16 as B
 
         def conv(t, w, b, slope, nchw=False, **kw):
@@ -114,10 +114,11 @@ class UNetDiscriminatorSN(nn.Module):
         x1, u1 = B.SkipForkFn16.apply(x1, 0.2)
         x2 = conv(u1, self.conv2.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
         x2, u2 = B.SkipForkFn16.apply(x2, 0.2)
-        x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True)
-        x4 = conv(B.Bilinear2xFn16.apply(x3), self.conv4.weight(), None, 0.2)
-        x5 = conv(B.Bilinear2xFn16.apply(x4, x2 if skip else None), self.conv5.weight(), None, 0.2)
-        x6 = conv(B.Bilinear2xFn16.apply(x5, x1 if skip else None), self.conv6.weight(), None, 0.2)
+        # conv3 / conv4 / conv5 feed only the resampling: its backward applies their LeakyReLU derivative (no stand-alone pass)
+        x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
+        x4 = conv(B.Bilinear2xFn16.apply(x3, None, 0.2), self.conv4.weight(), None, 0.2, grad_premasked=True)
+        x5 = conv(B.Bilinear2xFn16.apply(x4, x2 if skip else None, 0.2), self.conv5.weight(), None, 0.2, grad_premasked=True)
+        x6 = conv(B.Bilinear2xFn16.apply(x5, x1 if skip else None, 0.2), self.conv6.weight(), None, 0.2)
         if skip:
             x6 = B.AddFn16.apply(x6, x0)
         out = conv(x6, self.conv7.weight(), None, 0.2, grad_premasked=True)

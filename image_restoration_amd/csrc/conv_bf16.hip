@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void conv_fewcout_bf16_kernel(const ConvParams
     const int row = pix / XROW, col = pix - row * XROW;
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool valid = (pix < XPIX) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    xoff[r] = valid ? (((gy >> p.src_shift) * p.in_w + (gx >> p.src_shift)) * 32 + half * 16) : -1;
+    // LDS bank swizzle (as conv_tile_h): halves of staged pixel column c swapped when bit 3 of c is set; the readers undo it
+    xoff[r] = valid ? (((gy >> p.src_shift) * p.in_w + (gx >> p.src_shift)) * 32 + (half ^ ((col >> 3) & 1)) * 16) : -1;
   }
   // weight piece q of the chunk: tap = q / 8, cout = (q % 8) / 2, half = q % 2  ->  packed image [tap][32 couts][32 B]
   const int wq = wave * 64 + lane;
@@ -480,7 +481,8 @@ __global__ __launch_bounds__(256) void conv_fewcout_bf16_kernel(const ConvParams
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const char* xp = xs + ((2 * g + dy) * XROW + dx) * 32;
-          const bf16x8 a0 = *(const bf16x8*)xp, a1 = *(const bf16x8*)(xp + 16);
+          const int sw = (((pcol + dx) >> 3) & 1) * 16;
+          const bf16x8 a0 = *(const bf16x8*)(xp + sw), a1 = *(const bf16x8*)(xp + (sw ^ 16));
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 W0 = __builtin_bit_cast(s16x8, w0), W1 = __builtin_bit_cast(s16x8, w1);
           const s16x8 A0 = __builtin_bit_cast(s16x8, a0), A1 = __builtin_bit_cast(s16x8, a1);

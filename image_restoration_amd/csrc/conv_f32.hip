@@ -499,7 +499,10 @@ __global__ __launch_bounds__(256) void conv_fewcout_f32_kernel(const ConvParams 
     const int gy = y0 + p.tap_oy + row, gx = x0 + p.tap_ox + col;
     const bool valid = (pix < XPIX) && gy >= 0 && gy < p.vH && gx >= 0 && gx < p.vW;
     const int sy = ((gy * p.src_mul) >> p.src_shift) + p.src_oy, sx = ((gx * p.src_mul) >> p.src_shift) + p.src_ox;
-    xoff[r] = valid ? ((sy * p.in_w + sx) * 8 + half * 4) : -1;
+    // LDS bank swizzle (as conv_tile_f32): the two 16-byte halves of staged pixel column c are stored swapped when bit 3 of c is
+    // set, applied here by the source address; the readers below undo it.  The 32 lanes of a row stride 32 B, so without it every
+    // ds_read_b128 lane group hits each 16-byte bank slot twice (PMC round 2: 38 % of this kernel's LDS cycles were conflicts).
+    xoff[r] = valid ? ((sy * p.in_w + sx) * 8 + (half ^ ((col >> 3) & 1)) * 4) : -1;
   }
   // weight piece q of the chunk: tap = q/8, cout = (q%8)/2, half = q%2  ->  packed image [tap][32 couts][8]
   const int wq = wave * 64 + lane;
@@ -537,7 +540,8 @@ __global__ __launch_bounds__(256) void conv_fewcout_f32_kernel(const ConvParams 
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const char* xp = xs + ((2 * g + dy) * XROW + dx) * 32;
-          const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 16);
+          const int sw = (((pcol + dx) >> 3) & 1) * 16;  // where this column's first half lives
+          const f32x4 a0 = *(const f32x4*)(xp + sw), a1 = *(const f32x4*)(xp + (sw ^ 16));
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[e], a0[e], acc[g], 0, 0, 0);
 #pragma unroll

@@ -276,8 +276,14 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd16_kernel(const __bf16* __r
 // gsrc[y][x] = sum over the (at most 4x4) outputs whose taps touch (y, x): a gather, deterministic.  The (2 TH + 2) x (2 TW + 2)
 // window of output gradients of a source tile goes through the LDS once (coalesced), each thread then gathers the 4x4 block
 // of its source pixel from there; weights come from the forward's tap rule, so borders (clamped taps) need no special case.
+// MASK: the source was the LeakyReLU(slope) output `mask` of a layer with no other consumer of its pre-activation, so the gradient
+// leaves multiplied by that LeakyReLU's derivative (the stand-alone lrelu_bwd16 pass of that layer disappears); `plain` (optional)
+// also receives the unmasked gradient — what a skip connection added before the resampling gets.
+template <bool MASK>
 __global__ __launch_bounds__(256) void bilinear2x_bwd16_kernel(const __bf16* __restrict__ g, long long g_ns, __bf16* __restrict__ gsrc,
-                                                               long long gsrc_ns, int cblocks, int h, int w, int tiles_x, int tiles_y) {
+                                                               long long gsrc_ns, int cblocks, int h, int w, int tiles_x, int tiles_y,
+                                                               const __bf16* __restrict__ mask, long long mask_ns, float slope,
+                                                               __bf16* __restrict__ plain, long long plain_ns) {
   constexpr int GW = 2 * BIL_TW + 2, GH = 2 * BIL_TH + 2;
   __shared__ __attribute__((aligned(16))) __bf16 tile[GH * GW * 16];
   int t = blockIdx.x;
@@ -326,10 +332,22 @@ __global__ __launch_bounds__(256) void bilinear2x_bwd16_kernel(const __bf16* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
       }
+    const long long at = (((long long)cb * h + y) * w + x) * 16 + hf * 8;
     bf16x8_t o;
+    if constexpr (MASK) {
+      if (plain) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
-    *(bf16x8_t*)(gsrc + n * gsrc_ns + (((long long)cb * h + y) * w + x) * 16 + hf * 8) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+        *(bf16x8_t*)(plain + n * plain_ns + at) = o;
+      }
+      const bf16x8_t m = *(const bf16x8_t*)(mask + n * mask_ns + at);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)m[e] > 0.f ? acc[e] : acc[e] * slope);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+    }
+    *(bf16x8_t*)(gsrc + n * gsrc_ns + at) = o;
   }
 }
 
@@ -447,9 +465,23 @@ extern "C" int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_ns, void* gsrc, i
   const int tiles_x = (w + BIL_TW - 1) / BIL_TW, tiles_y = (h + BIL_TH - 1) / BIL_TH;
   const long long blocks = (long long)n * cblocks * tiles_x * tiles_y;
   SR_CHECK_ARG(blocks < (1ll << 31), "sr_bilinear2x_bwd_bf16: too many tiles");
-  hipLaunchKernelGGL(bilinear2x_bwd16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)g, (long long)g_ns,
-                     (__bf16*)gsrc, (long long)gsrc_ns, cblocks, h, w, tiles_x, tiles_y);
+  hipLaunchKernelGGL(bilinear2x_bwd16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)g, (long long)g_ns,
+                     (__bf16*)gsrc, (long long)gsrc_ns, cblocks, h, w, tiles_x, tiles_y, (const __bf16*)nullptr, 0ll, 1.f, (__bf16*)nullptr, 0ll);
   SR_CHECK_LAUNCH("bilinear2x_bwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_bilinear2x_bwd_lrelu_bf16(const void* g, int64_t g_ns, void* gsrc, int64_t gsrc_ns, const void* mask, int64_t mask_ns,
+                                            float slope, void* gplain, int64_t gplain_ns, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g && gsrc && mask && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_bilinear2x_bwd_lrelu_bf16: bad argument");
+  const int tiles_x = (w + BIL_TW - 1) / BIL_TW, tiles_y = (h + BIL_TH - 1) / BIL_TH;
+  const long long blocks = (long long)n * cblocks * tiles_x * tiles_y;
+  SR_CHECK_ARG(blocks < (1ll << 31), "sr_bilinear2x_bwd_lrelu_bf16: too many tiles");
+  hipLaunchKernelGGL(bilinear2x_bwd16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)g, (long long)g_ns,
+                     (__bf16*)gsrc, (long long)gsrc_ns, cblocks, h, w, tiles_x, tiles_y, (const __bf16*)mask, (long long)mask_ns, slope,
+                     (__bf16*)gplain, (long long)gplain_ns);
+  SR_CHECK_LAUNCH("bilinear2x_bwd16 (masked)");
   return SR_OK;
 }
 

@@ -184,10 +184,14 @@ class SkipForkFn16(torch.autograd.Function):
 
 class Bilinear2xFn16(torch.autograd.Function):
     """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB16 (sr_bilinear2x_{fwd,bwd}_bf16); with a
-    second input the resampled tensor is x + skip (the skip connection folded into the same pass)."""
+    second input the resampled tensor is x + skip (the skip connection folded into the same pass).
+
+    input_slope != 1: x is the LeakyReLU(input_slope) output of a conv whose only consumer this is; the backward then returns
+    dL/d(that conv's pre-activation) for x (sr_bilinear2x_bwd_lrelu_bf16: the derivative rides on the resampling gradient's
+    store) and the conv must be built with grad_premasked=True.  The skip input always receives the plain gradient."""
 
     @staticmethod
-    def forward(ctx, x, skip=None):
+    def forward(ctx, x, skip=None, input_slope=1.0):
         lib = _lib.load()
         x = x.contiguous()
         n, cb, h, w, _ = x.shape
@@ -200,6 +204,9 @@ class Bilinear2xFn16(torch.autograd.Function):
                                                   skip[0].numel() if skip is not None else 0, y.data_ptr(), y[0].numel(), n, cb, h,
                                                   w, _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
         ctx.has_skip = skip is not None
+        ctx.input_slope = input_slope
+        if input_slope != 1.0:
+            ctx.save_for_backward(x)
         return y
 
     @staticmethod
@@ -208,10 +215,20 @@ class Bilinear2xFn16(torch.autograd.Function):
         g = g.contiguous()
         n, cb, h2, w2, _ = g.shape
         gx = torch.empty((n, cb, h2 // 2, w2 // 2, 16), dtype=torch.bfloat16, device=g.device)
+        if ctx.input_slope != 1.0:
+            (x,) = ctx.saved_tensors
+            want_plain = ctx.has_skip and ctx.needs_input_grad[1]
+            gplain = torch.empty_like(gx) if want_plain else None
+            with torch.cuda.device(g.device):
+                _lib.check(lib.sr_bilinear2x_bwd_lrelu_bf16(g.data_ptr(), g[0].numel(), gx.data_ptr(), gx[0].numel(), x.data_ptr(),
+                                                            x[0].numel(), ctx.input_slope, gplain.data_ptr() if want_plain else None,
+                                                            gplain[0].numel() if want_plain else 0, n, cb, h2 // 2, w2 // 2,
+                                                            _stream(g.device)), 'sr_bilinear2x_bwd_lrelu_bf16')
+            return gx, gplain, None
         with torch.cuda.device(g.device):
             _lib.check(lib.sr_bilinear2x_bwd_bf16(g.data_ptr(), g[0].numel(), gx.data_ptr(), gx[0].numel(), n, cb, h2 // 2, w2 // 2,
                                                   _stream(g.device)), 'sr_bilinear2x_bwd_bf16')
-        return gx, (gx if ctx.has_skip else None)
+        return gx, (gx if ctx.has_skip else None), None
 
 
 class AddFn16(torch.autograd.Function):

@@ -435,6 +435,12 @@ int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_img_stride, const void* 
                            int64_t dst_img_stride, int n, int cblocks, int h, int w, void* stream);
 int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, int n, int cblocks, int h,
                            int w, void* stream);
+/* The same resampling gradient when the resampled tensor was the LeakyReLU(slope) output `mask` of a layer (UNetDiscriminatorSN's
+ * conv3 / conv4 / conv5): gsrc = lrelu'(mask) * gradient — that layer's stand-alone sr_lrelu_bwd_bf16 pass disappears — and, when
+ * gplain is not null, gplain = the gradient itself (what a skip connection added before the resampling receives). */
+int sr_bilinear2x_bwd_lrelu_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, const void* mask,
+                                 int64_t mask_img_stride, float slope, void* gplain, int64_t gplain_img_stride, int n, int cblocks,
+                                 int h, int w, void* stream);
 /* nn.BatchNorm2d + LeakyReLU of VGGStyleDiscriminator128 on CB16 activations (bf16 in / out; statistics, running
  * buffers, gamma / beta and their gradients fp32): twins of sr_bn_lrelu_{fwd,bwd}_f32, same arguments. */
 int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_img_stride, void* y, int64_t y_img_stride, int n, int c, int h, int w,

@@ -110,6 +110,22 @@ def test_shared_pass_ops_equal_their_separate_forms(cuda):
     sr_ = s.clone().requires_grad_(True)
     B.Bilinear2xFn16.apply(sr_).backward(gy)
     assert torch.equal(ar.grad, sr_.grad) and torch.equal(br.grad, sr_.grad)
+    # the resampling gradient carrying the LeakyReLU derivative of the conv that fed it (+ the plain gradient for the skip input):
+    # against the float64 resampling gradient of the same bf16 gradient, masked, to one bf16 rounding (the separate passes round twice)
+    xm = (torch.randn(2, 3, 12, 20, 16, generator=g) * 0.5).to(torch.bfloat16).to(cuda).requires_grad_(True)
+    km = b.clone().requires_grad_(True)
+    B.Bilinear2xFn16.apply(xm, km, 0.2).backward(gy)
+    assert torch.equal(km.grad, sr_.grad)                       # the skip input: the plain gradient, same bits as the unmasked kernel
+    def nchw(t):
+        return t.permute(0, 1, 4, 2, 3).reshape(t.size(0), -1, t.size(2), t.size(3))
+    ref_in = nchw(s.detach()).double().cpu().requires_grad_(True)
+    F.interpolate(ref_in, scale_factor=2, mode='bilinear', align_corners=False).backward(nchw(gy).double().cpu())
+    want_m = ref_in.grad * torch.where(nchw(xm.detach()).double().cpu() > 0, 1.0, 0.2)
+    got_m = nchw(xm.grad).double().cpu()
+    assert torch.all((got_m - want_m).abs() <= want_m.abs() * 2 ** -8 + 1e-6)
+    lone = xm.detach().clone().requires_grad_(True)
+    B.Bilinear2xFn16.apply(lone, None, 0.2).backward(gy)       # no skip input: masked output only
+    assert torch.equal(lone.grad, xm.grad)
     # fork: x [N, C/16, 2h, 2w, 16] -> (x, unshuffle(x)); backward of (g_skip, g_u)
     x = torch.randn(2, 2, 8, 12, 16, generator=g).to(torch.bfloat16).to(cuda).requires_grad_(True)
     xs, u = B.SkipForkFn16.apply(x, 0.2)
