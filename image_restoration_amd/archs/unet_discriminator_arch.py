@@ -99,28 +99,29 @@ class UNetDiscriminatorSN(nn.Module):
 
     def _forward_bf16(self, x):
         """Same network on CB16 bf16 activations.  Neighbouring layers share memory passes (hip_autograd_bf16.py): the
-        encoder activations fork into (skip, pixel-unshuffled conv input) with one fused gradient pass, the first two skip
+        encoder activations exist pixel-unshuffled only and fork into (skip, strided-conv input) with one fused gradient pass, the first two skip
         additions ride on the bilinear resampling, the resampling's backward applies the LeakyReLU derivative of the conv
         that fed it, and conv8 / conv9 apply their producer's LeakyReLU derivative in the data-gradient epilogue."""
         from .. import hip_autograd_bf16 as B
-
-        def conv(t, w, b, slope, nchw=False, **kw):
-            return B.ConvFn16.apply(t, w, b, slope, nchw, kw.get('pre_unshuffled', False), kw.get('input_slope', 1.0),
-                                    kw.get('grad_premasked', False))
         skip = self.skip_connection
-        x0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2, grad_premasked=True)
-        x0, u0 = B.SkipForkFn16.apply(x0, 0.2)
-        x1 = conv(u0, self.conv1.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
-        x1, u1 = B.SkipForkFn16.apply(x1, 0.2)
-        x2 = conv(u1, self.conv2.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
-        x2, u2 = B.SkipForkFn16.apply(x2, 0.2)
+        # x0, x1, x2 are stored pixel-unshuffled ONLY (u0, u1, u2: what the next strided conv reads): their producers write that
+        # layout from the epilogue and the skip consumers read it where it is — no unshuffle passes, no second copy
+        def conv(t, w, b, slope, nchw=False, **kw):   # noqa: F811 - adds the out_unshuffled option
+            return B.ConvFn16.apply(t, w, b, slope, nchw, kw.get('pre_unshuffled', False), kw.get('input_slope', 1.0),
+                                    kw.get('grad_premasked', False), kw.get('out_unshuffled', False))
+        u0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2, grad_premasked=True, out_unshuffled=True)
+        s0, u0 = B.ForkU2Fn16.apply(u0, 0.2)
+        u1 = conv(u0, self.conv1.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
+        s1, u1 = B.ForkU2Fn16.apply(u1, 0.2)
+        u2 = conv(u1, self.conv2.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
+        s2, u2 = B.ForkU2Fn16.apply(u2, 0.2)
         # conv3 / conv4 / conv5 feed only the resampling: its backward applies their LeakyReLU derivative (no stand-alone pass)
         x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
         x4 = conv(B.Bilinear2xFn16.apply(x3, None, 0.2), self.conv4.weight(), None, 0.2, grad_premasked=True)
-        x5 = conv(B.Bilinear2xFn16.apply(x4, x2 if skip else None, 0.2), self.conv5.weight(), None, 0.2, grad_premasked=True)
-        x6 = conv(B.Bilinear2xFn16.apply(x5, x1 if skip else None, 0.2), self.conv6.weight(), None, 0.2)
+        x5 = conv(B.Bilinear2xFn16.apply(x4, s2 if skip else None, 0.2, True), self.conv5.weight(), None, 0.2, grad_premasked=True)
+        x6 = conv(B.Bilinear2xFn16.apply(x5, s1 if skip else None, 0.2, True), self.conv6.weight(), None, 0.2)
         if skip:
-            x6 = B.AddFn16.apply(x6, x0)
+            x6 = B.AddFn16.apply(x6, s0, True)
         out = conv(x6, self.conv7.weight(), None, 0.2, grad_premasked=True)
         out = conv(out, self.conv8.weight(), None, 0.2, input_slope=0.2, grad_premasked=True)
         return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True, input_slope=0.2)  # fp32 NCHW logits

@@ -49,6 +49,7 @@ struct ConvParamsH {
   int s2_side;      // S2 kernels: 0 = parity of the input chunk decides the live taps, 1 = parity of the cout tile
   int src_shift;    // 1: nearest x2 upsample on the fly
   int mask_cbn;
+  int out_u2;       // 1: the CB16 destination is written pixel-unshuffled (sr_conv3x3_desc.out_unshuffle2)
   float slope, alpha, beta1, beta2, mask_slope;
   long long* dbg;  // development: per-workgroup phase clocks
 };
@@ -172,7 +173,9 @@ __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc
       for (int m = 0; m < 2; ++m) {
         const int cb = (cog * COT + c) * 2 + m;
         if (cb >= p.cout_blocks) continue;
-        const long long off = ((cb * HW + pixoff) * 16 + h * 8) * 2;
+        long long off = ((cb * HW + pixoff) * 16 + h * 8) * 2;
+        if (p.out_u2)  // plane (2 ry + rx) CB + cb of the half-resolution tensor (sr_conv3x3_desc.out_unshuffle2)
+          off = (((long long)((((y & 1) << 1) | (x & 1)) * p.cout_blocks + cb) * (HW >> 2) + (long long)(y >> 1) * (p.W >> 1) + (x >> 1)) * 16 + h * 8) * 2;
         const int b = m * 8;
         u32x4 o = {f2bf2(acc[c][r][b + 0], acc[c][r][b + 1]), f2bf2(acc[c][r][b + 2], acc[c][r][b + 3]),
                    f2bf2(acc[c][r][b + 4], acc[c][r][b + 5]), f2bf2(acc[c][r][b + 6], acc[c][r][b + 7])};
@@ -1613,8 +1616,16 @@ __global__ __launch_bounds__(512, 2) void conv_stream_bf16_kernel(const ConvPara
       auto s1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
       o = u32x4s{s0[0], s1[0], s0[1], s1[1]};
       // exec-masked where the column lies beyond the image: the instruction is issued either way (the waits count it)
-      if (vo != 0xfffffff0u)
-        store16(p.out + (long long)c.n * p.out_nb + (size_t)(cg * 2 + m) * oplane_b + vo + (unsigned)(r * p.W * 32), o, false);
+      if (vo != 0xfffffff0u) {
+        if (p.out_u2) {  // pixel-unshuffled destination: plane (2 ry + rx) CB + cb at half resolution
+          const int x = c.tx * 32 + j, y = c.ty * TH + wave * PT + r;
+          const size_t uo = (size_t)((((y & 1) << 1) | (x & 1)) * p.cout_blocks + cg * 2 + m) * (oplane_b >> 2) +
+                            (size_t)((y >> 1) * (p.W >> 1) + (x >> 1)) * 32 + h * 16;
+          store16(p.out + (long long)c.n * p.out_nb + uo, o, false);
+        } else {
+          store16(p.out + (long long)c.n * p.out_nb + (size_t)(cg * 2 + m) * oplane_b + vo + (unsigned)(r * p.W * 32), o, false);
+        }
+      }
     }
   };
 
@@ -1795,6 +1806,9 @@ static int fill_params_h(const sr_conv3x3_desc* d, ConvParamsH& p, const char* w
   p.beta1 = d->beta1;
   p.beta2 = d->beta2;
   p.dbg = nullptr;
+  p.out_u2 = d->out_unshuffle2 ? 1 : 0;
+  SR_CHECK_ARG(!p.out_u2 || (!d->out_nchw && d->cout % 16 == 0 && p.H % 2 == 0 && p.W % 2 == 0),
+               "%s: out_unshuffle2 needs a CB16 destination, cout %% 16 == 0 and an even output size (%dx%d, cout %d)", who, p.H, p.W, d->cout);
   SR_CHECK_ARG((long long)p.H * p.W * 32 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) < (1ll << 31),
                "%s: image too large for 32-bit plane offsets", who);
   return SR_OK;
@@ -1845,7 +1859,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   for (int k = 0; k < 5; ++k) {
     const sr_conv3x3_desc& c = d[k];
     if (c.in != d[0].in || c.in_img_stride != d[0].in_img_stride || c.n != n || c.in_h != h || c.in_w != w || c.upsample || c.out_nchw ||
-        c.s2_channels != 0 || c.cin_pad != 64 + 32 * k || c.cout != (k < 4 ? 32 : 64) || c.accumulate)
+        c.s2_channels != 0 || c.out_unshuffle2 || c.cin_pad != 64 + 32 * k || c.cout != (k < 4 ? 32 : 64) || c.accumulate)
       return SR_OK;
     if (k < 4 && ((const __bf16*)c.out != (const __bf16*)d[0].in + (64 + 32 * k) * hw || c.out_img_stride != d[0].in_img_stride ||
                   c.res1 || c.res2))
@@ -1977,7 +1991,7 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
                     !sr::prof_on();
   for (int k = 0; k < nconv && one_launch; ++k) {
     const sr_conv3x3_desc& c = d[k];
-    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 &&
+    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 && !c.out_unshuffle2 &&
                  c.cout <= 64 && c.cin_pad <= 256 && c.in_h % rows == 0;
   }
   const int conc = sr::launch_concurrency();

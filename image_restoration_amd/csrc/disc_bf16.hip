@@ -75,6 +75,8 @@ __global__ void add16_kernel(const __bf16* __restrict__ a, const __bf16* __restr
 // Gradient of an encoder activation x that feeds a skip connection and, pixel-unshuffled, the next 4x4/s2 convolution:
 //   dz = lrelu'(x) * (g_skip + unshuffle^-1(g_u))   in one pass (g_skip may be null; mask may be null = no LeakyReLU);
 // the sum is rounded to bf16 before the mask, like the separate add and LeakyReLU-backward passes it replaces.
+// MASK_U2: the activation only exists pixel-unshuffled (sr_conv3x3_desc.out_unshuffle2): the mask is read at g_u's index.
+template <bool MASK_U2>
 __global__ void fork_bwd16_kernel(const __bf16* __restrict__ g_skip, const __bf16* __restrict__ g_u, const __bf16* __restrict__ mask,
                                   __bf16* __restrict__ dz, float slope, int cblocks, int h, int w, long long total) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,12 +99,35 @@ __global__ void fork_bwd16_kernel(const __bf16* __restrict__ g_skip, const __bf1
     for (int e = 0; e < 8; ++e) s[e] = (__bf16)((float)s[e] + (float)k[e]);
   }
   if (mask) {
-    const bf16x8_t m = *(const bf16x8_t*)(mask + big);
+    const bf16x8_t m = *(const bf16x8_t*)(mask + (MASK_U2 ? small : big));
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (!((float)m[e] > 0.f)) s[e] = (__bf16)((float)s[e] * slope);
   }
   *(bf16x8_t*)(dz + big) = s;
+}
+
+// out = bf16(a + b) where b only exists pixel-unshuffled ([n][4 cblocks][h][w][16] standing for [n][cblocks][2h][2w][16]); thread =
+// 8 channels of one pixel of the plain tensors
+__global__ void add16_u2_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b_u2, __bf16* __restrict__ out, int cblocks, int h,
+                                int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int X = (int)(r % (2 * w));
+  r /= 2 * w;
+  const int Y = (int)(r % (2 * h));
+  r /= 2 * h;
+  const int cb = (int)(r % cblocks);
+  const long long n = r / cblocks;
+  const int par = (Y & 1) * 2 + (X & 1);
+  const long long small = (((n * 4 * cblocks + (long long)par * cblocks + cb) * h + (Y >> 1)) * w + (X >> 1)) * 16 + half * 8;
+  const bf16x8_t x = *(const bf16x8_t*)(a + i * 8), y = *(const bf16x8_t*)(b_u2 + small);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)x[e] + (float)y[e]);
+  *(bf16x8_t*)(out + i * 8) = o;
 }
 
 // y = x > 0 ? x : slope * x, 8 elements per thread (a stand-alone ReLU after a feature that is wanted before it)
@@ -198,6 +223,8 @@ __device__ __forceinline__ void bil_taps16(int o, int size, int& i0, int& i1, fl
 // A thread makes the 2x2 output block of one source pixel from its clamped 3x3 neighbourhood; the arithmetic per output is the
 // expression of the one-output form.
 constexpr int BIL_TH = 8, BIL_TW = 32;  // source tile of a workgroup (256 threads: one source pixel each, 16 channels in two passes)
+// SRC2_U2: src2 only exists pixel-unshuffled ([n][4 cblocks][h/2][w/2][16], sr_conv3x3_desc.out_unshuffle2; h, w even).
+template <bool SRC2_U2>
 __global__ __launch_bounds__(256) void bilinear2x_fwd16_kernel(const __bf16* __restrict__ src, long long src_ns,
                                                                const __bf16* __restrict__ src2, long long src2_ns,
                                                                __bf16* __restrict__ dst, long long dst_ns, int cblocks, int h, int w,
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd16_kernel(const __bf16* __r
   const int x0 = tx * BIL_TW, y0 = ty * BIL_TH;
   const long long plane = (long long)cb * h * w * 16;
   const __bf16* b = src + n * src_ns + plane;
-  const __bf16* c = src2 ? src2 + n * src2_ns + plane : nullptr;
+  const __bf16* c = src2 ? src2 + n * src2_ns + (SRC2_U2 ? 0 : plane) : nullptr;
   constexpr int PIECES = (BIL_TH + 2) * (BIL_TW + 2) * 2;
   for (int q = threadIdx.x; q < PIECES; q += 256) {
     const int pix = q >> 1, hf = q & 1;
@@ -224,7 +251,10 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd16_kernel(const __bf16* __r
     const long long off = ((long long)yy * w + xx) * 16 + hf * 8;
     bf16x8_t v = *(const bf16x8_t*)(b + off);
     if (c) {
-      const bf16x8_t u = *(const bf16x8_t*)(c + off);
+      long long off2 = off;
+      if constexpr (SRC2_U2)
+        off2 = ((((long long)(((yy & 1) << 1) | (xx & 1)) * cblocks + cb) * (h >> 1) + (yy >> 1)) * (w >> 1) + (xx >> 1)) * 16 + hf * 8;
+      const bf16x8_t u = *(const bf16x8_t*)(c + off2);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)u[e]);
     }
@@ -430,9 +460,20 @@ extern "C" int sr_cb16_fork_bwd_bf16(const void* g_skip, const void* g_u, const 
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(g_u && dz && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_fork_bwd_bf16: bad argument");
   const long long total = (long long)n * cblocks * 2 * h * 2 * w * 2;
-  hipLaunchKernelGGL(fork_bwd16_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g_skip, (const __bf16*)g_u,
+  hipLaunchKernelGGL(fork_bwd16_kernel<false>, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g_skip, (const __bf16*)g_u,
                      (const __bf16*)mask, (__bf16*)dz, slope, cblocks, h, w, total);
   SR_CHECK_LAUNCH("fork_bwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_cb16_fork_bwd_u2_bf16(const void* g_skip, const void* g_u, const void* mask_u2, void* dz, float slope, int n, int cblocks,
+                                        int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(g_u && mask_u2 && dz && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_fork_bwd_u2_bf16: bad argument");
+  const long long total = (long long)n * cblocks * 2 * h * 2 * w * 2;
+  hipLaunchKernelGGL(fork_bwd16_kernel<true>, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g_skip, (const __bf16*)g_u,
+                     (const __bf16*)mask_u2, (__bf16*)dz, slope, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("fork_bwd16 (u2 mask)");
   return SR_OK;
 }
 
@@ -452,9 +493,33 @@ extern "C" int sr_bilinear2x_fwd_bf16(const void* src, int64_t src_ns, const voi
   const int tiles_x = (w + BIL_TW - 1) / BIL_TW, tiles_y = (h + BIL_TH - 1) / BIL_TH;
   const long long blocks = (long long)n * cblocks * tiles_x * tiles_y;
   SR_CHECK_ARG(blocks < (1ll << 31), "sr_bilinear2x_fwd_bf16: too many tiles");
-  hipLaunchKernelGGL(bilinear2x_fwd16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)src, (long long)src_ns,
+  hipLaunchKernelGGL(bilinear2x_fwd16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)src, (long long)src_ns,
                      (const __bf16*)src2, (long long)src2_ns, (__bf16*)dst, (long long)dst_ns, cblocks, h, w, tiles_x, tiles_y);
   SR_CHECK_LAUNCH("bilinear2x_fwd16");
+  return SR_OK;
+}
+
+extern "C" int sr_bilinear2x_fwd_u2_bf16(const void* src, int64_t src_ns, const void* src2_u2, int64_t src2_ns, void* dst, int64_t dst_ns,
+                                         int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(src && src2_u2 && dst && n > 0 && cblocks > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0,
+               "sr_bilinear2x_fwd_u2_bf16: bad argument (the source size must be even)");
+  const int tiles_x = (w + BIL_TW - 1) / BIL_TW, tiles_y = (h + BIL_TH - 1) / BIL_TH;
+  const long long blocks = (long long)n * cblocks * tiles_x * tiles_y;
+  SR_CHECK_ARG(blocks < (1ll << 31), "sr_bilinear2x_fwd_u2_bf16: too many tiles");
+  hipLaunchKernelGGL(bilinear2x_fwd16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)src, (long long)src_ns,
+                     (const __bf16*)src2_u2, (long long)src2_ns, (__bf16*)dst, (long long)dst_ns, cblocks, h, w, tiles_x, tiles_y);
+  SR_CHECK_LAUNCH("bilinear2x_fwd16 (u2 skip)");
+  return SR_OK;
+}
+
+extern "C" int sr_cb16_add_u2_bf16(const void* a, const void* b_u2, void* out, int n, int cblocks, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(a && b_u2 && out && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_cb16_add_u2_bf16: bad argument");
+  const long long total = (long long)n * cblocks * 4 * h * w * 2;
+  hipLaunchKernelGGL(add16_u2_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)a, (const __bf16*)b_u2, (__bf16*)out, cblocks, h,
+                     w, total);
+  SR_CHECK_LAUNCH("add16 (u2)");
   return SR_OK;
 }
 

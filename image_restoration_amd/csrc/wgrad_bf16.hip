@@ -717,8 +717,11 @@ struct RdbPlan {
   int row_item[32], row_pair0[32], row_a[32];
   long long pairs;
 };
-// Greedy packing, largest rows first: a row joins the first item with room for its pairs (<= 8), a free dY slot (<= 2)
-// and the same first cin tile.  Returns false if the block needs more than 8 items.
+// Greedy packing, largest rows first: a row joins an item with room for its pairs (<= 8), a free dY slot (<= 2) and the same first
+// cin tile — among those the one that ends up staging the FEWEST tile rows per step (X tiles + dY tiles).  The kernel runs at the
+// rate its workgroups can stage rows (its waves sit blocked in LDS-DMA issue for a quarter of a step, tools/rdb_wgrad_phase.py) and
+// every workgroup walks the same number of rows, so the item that stages the most per row sets the launch time: first-fit gave
+// {conv5 t0, conv1} 8 tile rows against {conv3} 5; this gives 7 / 7 / 7 / 6.  Returns false if the block needs more than 8 items.
 bool rdb_plan(int nf, int gc, float* const* dparams, RdbPlan* P) {
   const int nfp = (nf + 15) / 16 * 16, gcp = (gc + 15) / 16 * 16;
   P->nitems = P->nrows = 0;
@@ -743,10 +746,15 @@ bool rdb_plan(int nf, int gc, float* const* dparams, RdbPlan* P) {
   }
   for (int ri = 0; ri < P->nrows; ++ri) {
     const RdbRow& r = P->rows[ri];
-    int dst = -1;
-    for (int i = 0; i < P->nitems && dst < 0; ++i) {
+    int dst = -1, best = 1 << 30;
+    for (int i = 0; i < P->nitems; ++i) {
       const RdbItem& im = P->items[i];
-      if (im.npairs + r.nx <= 8 && im.ndy < 2 && im.x_tile0 == r.x_tile0) dst = i;
+      if (!(im.npairs + r.nx <= 8 && im.ndy < 2 && im.x_tile0 == r.x_tile0)) continue;
+      const int staged = (im.nx > r.nx ? im.nx : r.nx) + im.ndy + 1;
+      if (staged < best) {
+        best = staged;
+        dst = i;
+      }
     }
     if (dst < 0) {
       if (P->nitems >= 8) return false;

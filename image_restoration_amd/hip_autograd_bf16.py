@@ -82,11 +82,16 @@ class ConvFn16(torch.autograd.Function):
       input_slope      != 1: the input is the LeakyReLU(input_slope) output of a layer with no other consumer, so the data
                        gradient is multiplied by that LeakyReLU's derivative in the conv's epilogue (mask = the input) and
                        the producer must be built with grad_premasked=True;
-      grad_premasked   the gradient arriving for this conv's output already carries its LeakyReLU derivative.
+      grad_premasked   the gradient arriving for this conv's output already carries its LeakyReLU derivative;
+      out_unshuffled   the output is stored pixel-unshuffled ONLY ([N, 4C/16, H/2, W/2, 16]: what the next 4x4/s2 conv reads;
+                       sr_conv3x3_desc.out_unshuffle2) and handed to ForkU2Fn16.  Convention for such tensors: their GRADIENT
+                       travels in the plain layout ([N, C/16, H, W, 16] bytes) under the unshuffled shape — same element count, and
+                       every producer / consumer of it is one of this module's functions.
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act_slope, out_nchw, pre_unshuffled=False, input_slope=1.0, grad_premasked=False):
+    def forward(ctx, x, weight, bias, act_slope, out_nchw, pre_unshuffled=False, input_slope=1.0, grad_premasked=False,
+                out_unshuffled=False):
         k = weight.size(2)
         weight = weight.detach().contiguous().float()
         cout, cin = weight.shape[:2]
@@ -106,13 +111,15 @@ class ConvFn16(torch.autograd.Function):
             saved_y = None
             ret = y
         else:
-            out = H.conv3x3_bf16(src, pc, act_slope=act_slope, s2_channels=s2)
-            saved_y = out.buf if act_slope != 1.0 else None
+            out = H.conv3x3_bf16(src, pc, act_slope=act_slope, s2_channels=s2, out_unshuffle2=out_unshuffled)
+            assert not out_unshuffled or grad_premasked, 'the fork applies the LeakyReLU derivative of an unshuffled output'
+            saved_y = out.buf if (act_slope != 1.0 and not grad_premasked) else None
             ret = out.buf
         ctx.save_for_backward(src.buf, w3, saved_y)
         ctx.act_slope, ctx.has_bias, ctx.k, ctx.out_nchw = act_slope, bias is not None, k, out_nchw
         ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
         ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked, ctx.s2 = pre_unshuffled, input_slope, grad_premasked, s2
+        ctx.out_unshuffled = out_unshuffled
         assert input_slope == 1.0 or k == 3, 'the input mask applies to 3x3 convs'
         return ret
 
@@ -127,6 +134,9 @@ class ConvFn16(torch.autograd.Function):
             dzc = H.nchw_to_cb16(gy.contiguous().float())
         else:
             gy = gy.contiguous()
+            if ctx.out_unshuffled:  # plain-layout gradient under the unshuffled shape (see the class docstring)
+                n_, cb4, hh, ww, _ = gy.shape
+                gy = gy.view(n_, cb4 // 4, 2 * hh, 2 * ww, 16)
             if y is not None and not ctx.grad_premasked:
                 dz = torch.empty_like(gy)
                 with torch.cuda.device(dev):
@@ -149,7 +159,7 @@ class ConvFn16(torch.autograd.Function):
             dw, db = H.conv3x3_wgrad_bf16(src, dzc, cout, cin3, want_bias=ctx.has_bias)
             if ctx.k == 4:
                 dw = _dw3_to_dw4(dw, ctx.cout, ctx.cin)
-        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
+        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None, None
 
 
 class SkipForkFn16(torch.autograd.Function):
@@ -182,28 +192,66 @@ class SkipForkFn16(torch.autograd.Function):
         return dz, None
 
 
+class ForkU2Fn16(torch.autograd.Function):
+    """An encoder activation that only exists pixel-unshuffled (ConvFn16(out_unshuffled=True)) and feeds a skip connection and
+    the next 4x4/s2 conv: forward hands the same tensor to both (no kernel, no copy); backward is SkipForkFn16's one pass with the
+    LeakyReLU mask read from the unshuffled tensor (sr_cb16_fork_bwd_u2_bf16).  Gradients of such tensors travel in the PLAIN
+    layout under the unshuffled shape (ConvFn16 docstring): g_skip arrives that way from Bilinear2xFn16 / AddFn16, the result
+    leaves that way for the producing conv; g_u is the strided conv's genuine unshuffled gradient."""
+
+    @staticmethod
+    def forward(ctx, u, slope):
+        u = u.contiguous()
+        ctx.save_for_backward(u)
+        ctx.slope = slope
+        ctx.set_materialize_grads(False)
+        return u.view_as(u), u.view_as(u)
+
+    @staticmethod
+    def backward(ctx, g_skip, g_u):
+        lib = _lib.load()
+        (u,) = ctx.saved_tensors
+        n, cb4, h, w, _ = u.shape
+        if g_u is None:
+            g_u = torch.zeros_like(u)
+        dz = torch.empty_like(u)   # plain layout [n, cb4 / 4, 2h, 2w, 16] under u's shape
+        g_skip = g_skip.contiguous() if g_skip is not None else None
+        with torch.cuda.device(u.device):
+            _lib.check(lib.sr_cb16_fork_bwd_u2_bf16(g_skip.data_ptr() if g_skip is not None else None, g_u.contiguous().data_ptr(),
+                                                    u.data_ptr(), dz.data_ptr(), ctx.slope, n, cb4 // 4, h, w, _stream(u.device)),
+                       'sr_cb16_fork_bwd_u2_bf16')
+        return dz, None
+
+
 class Bilinear2xFn16(torch.autograd.Function):
     """F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on CB16 (sr_bilinear2x_{fwd,bwd}_bf16); with a
     second input the resampled tensor is x + skip (the skip connection folded into the same pass).
 
     input_slope != 1: x is the LeakyReLU(input_slope) output of a conv whose only consumer this is; the backward then returns
     dL/d(that conv's pre-activation) for x (sr_bilinear2x_bwd_lrelu_bf16: the derivative rides on the resampling gradient's
-    store) and the conv must be built with grad_premasked=True.  The skip input always receives the plain gradient."""
+    store) and the conv must be built with grad_premasked=True.  The skip input always receives the plain gradient.
+    skip_u2: the skip input only exists pixel-unshuffled (ForkU2Fn16); it is read where it is (sr_bilinear2x_fwd_u2_bf16) and its
+    gradient goes back in the plain layout under the unshuffled shape."""
 
     @staticmethod
-    def forward(ctx, x, skip=None, input_slope=1.0):
+    def forward(ctx, x, skip=None, input_slope=1.0, skip_u2=False):
         lib = _lib.load()
         x = x.contiguous()
         n, cb, h, w, _ = x.shape
+        y = torch.empty((n, cb, 2 * h, 2 * w, 16), dtype=torch.bfloat16, device=x.device)
         if skip is not None:
             skip = skip.contiguous()
-            assert skip.shape == x.shape
-        y = torch.empty((n, cb, 2 * h, 2 * w, 16), dtype=torch.bfloat16, device=x.device)
+            assert skip.shape == ((n, 4 * cb, h // 2, w // 2, 16) if skip_u2 else x.shape)
         with torch.cuda.device(x.device):
-            _lib.check(lib.sr_bilinear2x_fwd_bf16(x.data_ptr(), x[0].numel(), skip.data_ptr() if skip is not None else None,
-                                                  skip[0].numel() if skip is not None else 0, y.data_ptr(), y[0].numel(), n, cb, h,
-                                                  w, _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
+            if skip is not None and skip_u2:
+                _lib.check(lib.sr_bilinear2x_fwd_u2_bf16(x.data_ptr(), x[0].numel(), skip.data_ptr(), skip[0].numel(), y.data_ptr(),
+                                                         y[0].numel(), n, cb, h, w, _stream(x.device)), 'sr_bilinear2x_fwd_u2_bf16')
+            else:
+                _lib.check(lib.sr_bilinear2x_fwd_bf16(x.data_ptr(), x[0].numel(), skip.data_ptr() if skip is not None else None,
+                                                      skip[0].numel() if skip is not None else 0, y.data_ptr(), y[0].numel(), n, cb, h,
+                                                      w, _stream(x.device)), 'sr_bilinear2x_fwd_bf16')
         ctx.has_skip = skip is not None
+        ctx.skip_shape = tuple(skip.shape) if skip is not None else None
         ctx.input_slope = input_slope
         if input_slope != 1.0:
             ctx.save_for_backward(x)
@@ -224,30 +272,38 @@ class Bilinear2xFn16(torch.autograd.Function):
                                                             x[0].numel(), ctx.input_slope, gplain.data_ptr() if want_plain else None,
                                                             gplain[0].numel() if want_plain else 0, n, cb, h2 // 2, w2 // 2,
                                                             _stream(g.device)), 'sr_bilinear2x_bwd_lrelu_bf16')
-            return gx, gplain, None
+            return gx, (gplain.view(ctx.skip_shape) if want_plain else None), None, None
         with torch.cuda.device(g.device):
             _lib.check(lib.sr_bilinear2x_bwd_bf16(g.data_ptr(), g[0].numel(), gx.data_ptr(), gx[0].numel(), n, cb, h2 // 2, w2 // 2,
                                                   _stream(g.device)), 'sr_bilinear2x_bwd_bf16')
-        return gx, (gx if ctx.has_skip else None), None
+        return gx, (gx.view(ctx.skip_shape) if ctx.has_skip else None), None, None
 
 
 class AddFn16(torch.autograd.Function):
-    """a + b on CB16 (skip connections) in one pass: sr_cb16_add_bf16."""
+    """a + b on CB16 (skip connections) in one pass: sr_cb16_add_bf16; b_u2: b only exists pixel-unshuffled (ForkU2Fn16) and is read
+    where it is (sr_cb16_add_u2_bf16), its gradient goes back in the plain layout under the unshuffled shape."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, b_u2=False):
         lib = _lib.load()
         a, b = a.contiguous(), b.contiguous()
-        assert a.shape == b.shape
         out = torch.empty_like(a)
+        ctx.b_shape = tuple(b.shape)
         with torch.cuda.device(a.device):
-            _lib.check(lib.sr_cb16_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a.device)),
-                       'sr_cb16_add_bf16')
+            if b_u2:
+                n, cb, h2, w2, _ = a.shape
+                assert b.shape == (n, 4 * cb, h2 // 2, w2 // 2, 16)
+                _lib.check(lib.sr_cb16_add_u2_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, cb, h2 // 2, w2 // 2, _stream(a.device)),
+                           'sr_cb16_add_u2_bf16')
+            else:
+                assert a.shape == b.shape
+                _lib.check(lib.sr_cb16_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a.device)),
+                           'sr_cb16_add_bf16')
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, g
+        return g, g.view(ctx.b_shape), None
 
 
 class MaxPool2x2Fn16(torch.autograd.Function):

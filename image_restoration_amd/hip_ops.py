@@ -406,7 +406,7 @@ class PackedConvBF16:
 
 
 def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-                    beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0):
+                    beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0, out_unshuffle2=False):
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
     H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
     d = _lib.ConvDesc()
@@ -418,6 +418,12 @@ def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1
         assert out_nchw.is_contiguous() and out_nchw.dtype == torch.float32 and out_nchw.shape == (src.n, pc.cout, H, W)
         d.out, d.out_img_stride, d.out_nchw = out_nchw.data_ptr(), pc.cout * H * W, 1
         ret = out_nchw
+    elif out_unshuffle2:
+        # the destination only exists pixel-unshuffled: [n][4 cout / 16][H / 2][W / 2][16] (sr_conv3x3_desc.out_unshuffle2)
+        assert out is None and pc.cout % 16 == 0 and H % 2 == 0 and W % 2 == 0
+        out = CB16.empty(src.n, 4 * pc.cout, H // 2, W // 2, src.device)
+        d.out, d.out_img_stride, d.out_nchw, d.out_unshuffle2 = out.ptr, out.img_stride, 0, 1
+        ret = out
     else:
         if out is None:
             out = CB16.empty(src.n, pc.cout, H, W, src.device)  # every valid block is written (pad couts: zero weights)
@@ -437,7 +443,8 @@ def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1
 def conv3x3_bf16(src, pc, out=None, **kw):
     """bf16 twin of conv3x3 (fp32 accumulation and epilogue, bf16 CB16 or fp32 NCHW output) — sr_conv3x3_bf16.
     Keywords: upsample, act_slope, alpha, res1/beta1, res2/beta2, out_nchw, mask/mask_slope, s2_channels/s2_side
-    (s2_channels = C marks a 4x4/s2 conv carried on a pixel-unshuffled operand of 4C channels: zero taps are skipped)."""
+    (s2_channels = C marks a 4x4/s2 conv carried on a pixel-unshuffled operand of 4C channels: zero taps are skipped),
+    out_unshuffle2 (the result is stored pixel-unshuffled only: [n][4 cout / 16][H / 2][W / 2][16])."""
     lib = _lib.load()
     d, ret = _conv_desc_bf16(src, pc, out, **kw)
     with torch.cuda.device(src.device):

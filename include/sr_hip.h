@@ -40,7 +40,7 @@ extern "C" {
 #define SR_ELAUNCH (-2)  /* HIP launch/runtime error */
 #define SR_ENOSPACE (-3) /* workspace too small */
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 
 /* ABI version of this library (SR_ABI_VERSION it was built with). */
 int sr_version(void);
@@ -123,6 +123,10 @@ typedef struct sr_conv3x3_desc {
                              16-channel blocks only 2x2 of the 9 taps have non-zero weights and the kernel skips the rest
                              (same result: the skipped products are exact zeros) */
   int s2_side;            /* 0: the parity classes are the input channels (forward); 1: the output channels (data gradient) */
+  int out_unshuffle2;     /* sr_conv3x3_bf16 only (ABI 2).  1: the CB16 destination is written PIXEL-UNSHUFFLED — out[n][(2 ry + rx) CB + cb]
+                             [y / 2][x / 2][16] with ry = y & 1, rx = x & 1, CB = cout / 16 (cout % 16 == 0, even output H and W): the layout
+                             sr_cb16_unshuffle2_bf16 produces and the next 4x4 / stride-2 conv of a U-Net encoder reads, so the activation
+                             is never stored in the plain layout at all (the *_u2 entry points below read it where it is) */
 } sr_conv3x3_desc;
 
 /* Fused 3x3 / stride 1 / pad 1 convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -441,6 +445,16 @@ int sr_bilinear2x_bwd_bf16(const void* g, int64_t g_img_stride, void* gsrc, int6
 int sr_bilinear2x_bwd_lrelu_bf16(const void* g, int64_t g_img_stride, void* gsrc, int64_t gsrc_img_stride, const void* mask,
                                  int64_t mask_img_stride, float slope, void* gplain, int64_t gplain_img_stride, int n, int cblocks,
                                  int h, int w, void* stream);
+/* Readers of an activation that only exists pixel-unshuffled (sr_conv3x3_desc.out_unshuffle2; `u2` arguments are
+ * [n][4 cblocks][h][w][16] tensors standing for a plain [n][cblocks][2h][2w][16] one):
+ *   sr_cb16_add_u2_bf16          out = a + b_u2                       (a, out plain [2h][2w]; UNet: x6 + x0)
+ *   sr_bilinear2x_fwd_u2_bf16    dst = bilinear_x2(src + src2_u2)     (src plain [2h][2w], dst [4h][4w]; UNet: up(x4 + x2), up(x5 + x1))
+ *   sr_cb16_fork_bwd_u2_bf16     sr_cb16_fork_bwd_bf16 with the LeakyReLU mask read from the u2 tensor (same index as g_u) */
+int sr_cb16_add_u2_bf16(const void* a, const void* b_u2, void* out, int n, int cblocks, int h, int w, void* stream);
+int sr_bilinear2x_fwd_u2_bf16(const void* src, int64_t src_img_stride, const void* src2_u2, int64_t src2_img_stride, void* dst,
+                              int64_t dst_img_stride, int n, int cblocks, int h, int w, void* stream);
+int sr_cb16_fork_bwd_u2_bf16(const void* g_skip, const void* g_u, const void* mask_u2, void* dz, float slope, int n, int cblocks, int h,
+                             int w, void* stream);
 /* nn.BatchNorm2d + LeakyReLU of VGGStyleDiscriminator128 on CB16 activations (bf16 in / out; statistics, running
  * buffers, gamma / beta and their gradients fp32): twins of sr_bn_lrelu_{fwd,bwd}_f32, same arguments. */
 int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_img_stride, void* y, int64_t y_img_stride, int n, int c, int h, int w,

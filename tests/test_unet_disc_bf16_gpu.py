@@ -322,3 +322,53 @@ def test_unet_bf16_equals_a_float64_model_of_bf16_storage(cuda):
     for name, p in (('conv0.weight', net.conv0.weight), ('conv0.bias', net.conv0.bias), ('conv9.weight', net.conv9.weight),
                     ('conv9.bias', net.conv9.bias)):
         assert rel(p.grad, w[name].grad) < 3e-2, name
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [
+    (2, 64, 64, 32, 48),      # per-tile kernel, small launch (4-wave tiles)
+    (4, 128, 128, 64, 96),    # per-tile kernel, 8-wave tiles, two cout groups
+    (12, 16, 64, 512, 512),   # streaming kernel (few input channels on a large grid): the U-Net's conv0 at its training size
+    (3, 48, 32, 18, 22),      # ragged: partly filled tiles, 32 couts
+])
+def test_conv_stores_its_output_pixel_unshuffled_only(cuda, n, cin, cout, h, w):
+    """sr_conv3x3_desc.out_unshuffle2: the epilogue writes out[n][(2 ry + rx) CB + cb][y / 2][x / 2] — bit for bit the pixel unshuffle
+    (sr_cb16_unshuffle2_bf16) of the plainly stored result, for the per-tile and the streaming kernel."""
+    g = torch.Generator().manual_seed(n + cin)
+    x = H.CB16(torch.randn(n, cin // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda))
+    pc = H.PackedConvBF16((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(cuda), (torch.randn(cout, generator=g) * 0.1).to(cuda))
+    plain = H.conv3x3_bf16(x, pc, act_slope=0.2).buf
+    u = H.conv3x3_bf16(x, pc, act_slope=0.2, out_unshuffle2=True).buf
+    assert u.shape == (n, 4 * cout // 16, h // 2, w // 2, 16)
+    assert torch.equal(u, B._unshuffle2(plain))
+
+
+def test_readers_of_unshuffled_only_activations_equal_their_plain_forms(cuda):
+    """sr_cb16_add_u2_bf16, sr_bilinear2x_fwd_u2_bf16 and sr_cb16_fork_bwd_u2_bf16 read an activation that only exists
+    pixel-unshuffled: same bits as the plain-layout kernels on the shuffled-back tensor; the autograd functions pass gradients of
+    such tensors in the plain layout under the unshuffled shape."""
+    g = torch.Generator().manual_seed(11)
+    n, cb, h2, w2 = 2, 3, 12, 20
+    a = torch.randn(n, cb, h2, w2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    b = torch.randn(n, cb, h2, w2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    bu = B._unshuffle2(b)
+    assert torch.equal(B.AddFn16.apply(a, bu, True), B.AddFn16.apply(a, b))
+    assert torch.equal(B.Bilinear2xFn16.apply(a, bu, 1.0, True), B.Bilinear2xFn16.apply(a, b))
+    # gradients: the skip input's gradient comes back plain-layout under bu's shape
+    ar, bur = a.clone().requires_grad_(True), bu.clone().requires_grad_(True)
+    gy = torch.randn(n, cb, 2 * h2, 2 * w2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    B.Bilinear2xFn16.apply(ar, bur, 0.2, True).backward(gy)
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    B.Bilinear2xFn16.apply(a2, b2, 0.2).backward(gy)
+    assert torch.equal(ar.grad, a2.grad) and bur.grad.shape == bu.shape and torch.equal(bur.grad.view(b.shape), b2.grad)
+    # fork: u -> (skip handle, strided-conv input); backward of (g_skip plain-under-u-shape, g_u)
+    x = torch.randn(n, cb, h2, w2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    u = B._unshuffle2(x).requires_grad_(True)
+    s_, c_ = B.ForkU2Fn16.apply(u, 0.2)
+    assert s_.data_ptr() == u.data_ptr() and c_.data_ptr() == u.data_ptr()      # no copy
+    g_skip = torch.randn(n, cb, h2, w2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    g_u = torch.randn(n, 4 * cb, h2 // 2, w2 // 2, 16, generator=g).to(torch.bfloat16).to(cuda)
+    torch.autograd.backward([s_, c_], [g_skip.view(u.shape), g_u])
+    xr = x.clone().requires_grad_(True)
+    xs, xu = B.SkipForkFn16.apply(xr, 0.2)
+    torch.autograd.backward([xs, xu], [g_skip, g_u])
+    assert torch.equal(u.grad.view(x.shape), xr.grad)
