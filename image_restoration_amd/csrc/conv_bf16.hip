@@ -1617,7 +1617,8 @@ __global__ __launch_bounds__(512, 2) void conv_stream_bf16_kernel(const ConvPara
       o = u32x4s{s0[0], s1[0], s0[1], s1[1]};
       // exec-masked where the column lies beyond the image: the instruction is issued either way (the waits count it)
       if (vo != 0xfffffff0u) {
-        if (p.out_u2) {  // pixel-unshuffled destination: plane (2 ry + rx) CB + cb at half resolution
+        // (only the one-chunk instance without an extra operand — the U-Net's conv0 — offers it: the deeper ones have no registers to spare)
+        if (NC == 1 && !AUX && p.out_u2) {  // pixel-unshuffled destination: plane (2 ry + rx) CB + cb at half resolution
           const int x = c.tx * 32 + j, y = c.ty * TH + wave * PT + r;
           const size_t uo = (size_t)((((y & 1) << 1) | (x & 1)) * p.cout_blocks + cg * 2 + m) * (oplane_b >> 2) +
                             (size_t)((y >> 1) * (p.W >> 1) + (x >> 1)) * 32 + h * 16;
@@ -2090,7 +2091,8 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   if (g_stream_enabled && p.cin_blocks <= 4 && d->cout == 64 && d->s2_channels == 0 && p.H % 16 == 0) {
     const int naux = (d->res1 ? 1 : 0) + (d->res2 ? 1 : 0) + (d->mask_src ? 1 : 0);
     int dev = 0, cus = 0;
-    if (naux <= 1 && !(naux == 1 && p.cin_blocks == 2) /* that instance spills */ && (!d->mask_src || d->mask_cbn >= 4) && hipGetDevice(&dev) == hipSuccess &&
+    if (naux <= 1 && !(naux == 1 && p.cin_blocks == 2) /* that instance spills */ && (!d->mask_src || d->mask_cbn >= 4) &&
+        (!p.out_u2 || (naux == 0 && p.cin_blocks == 1)) && hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
       const int conc0 = sr::launch_concurrency();
       const int grid = cus / (conc0 > 1 ? conc0 : 1);
