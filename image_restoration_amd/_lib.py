@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ('res2', C.c_void_p), ('res2_img_stride', C.c_int64), ('beta2', C.c_float), ('res_cbn', C.c_int),
         ('out_h', C.c_int), ('out_w', C.c_int), ('accumulate', C.c_int), ('mask_src', C.c_void_p), ('mask_img_stride', C.c_int64),
         ('mask_cb0', C.c_int), ('mask_cbn', C.c_int), ('mask_slope', C.c_float), ('s2_channels', C.c_int), ('s2_side', C.c_int),
-        ('out_unshuffle2', C.c_int),
+        ('out_unshuffle2', C.c_int), ('res1_u2', C.c_int), ('res1_keep_sign', C.c_int),
     ]
 
 
@@ -168,6 +168,8 @@ SIGNATURES = {
                                             C.c_int, C.c_int, C.c_void_p]),
     'sr_cb16_fork_bwd_u2_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]),
+    'sr_lrelu_bwd_diff_u2_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p]),
     'sr_bn_lrelu_fwd_bf16': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

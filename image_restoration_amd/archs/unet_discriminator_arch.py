@@ -108,7 +108,7 @@ class UNetDiscriminatorSN(nn.Module):
         # layout from the epilogue and the skip consumers read it where it is — no unshuffle passes, no second copy
         def conv(t, w, b, slope, nchw=False, **kw):   # noqa: F811 - adds the out_unshuffled option
             return B.ConvFn16.apply(t, w, b, slope, nchw, kw.get('pre_unshuffled', False), kw.get('input_slope', 1.0),
-                                    kw.get('grad_premasked', False), kw.get('out_unshuffled', False))
+                                    kw.get('grad_premasked', False), kw.get('out_unshuffled', False), kw.get('skip_u2'))
         u0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2, grad_premasked=True, out_unshuffled=True)
         s0, u0 = B.ForkU2Fn16.apply(u0, 0.2)
         u1 = conv(u0, self.conv1.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
@@ -119,9 +119,8 @@ class UNetDiscriminatorSN(nn.Module):
         x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
         x4 = conv(B.Bilinear2xFn16.apply(x3, None, 0.2), self.conv4.weight(), None, 0.2, grad_premasked=True)
         x5 = conv(B.Bilinear2xFn16.apply(x4, s2 if skip else None, 0.2, True), self.conv5.weight(), None, 0.2, grad_premasked=True)
-        x6 = conv(B.Bilinear2xFn16.apply(x5, s1 if skip else None, 0.2, True), self.conv6.weight(), None, 0.2)
-        if skip:
-            x6 = B.AddFn16.apply(x6, s0, True)
+        # conv6 adds the last skip in its epilogue (sign-keeping rounding: its LeakyReLU mask is recovered from the sum and x0)
+        x6 = conv(B.Bilinear2xFn16.apply(x5, s1 if skip else None, 0.2, True), self.conv6.weight(), None, 0.2, skip_u2=s0 if skip else None)
         out = conv(x6, self.conv7.weight(), None, 0.2, grad_premasked=True)
         out = conv(out, self.conv8.weight(), None, 0.2, input_slope=0.2, grad_premasked=True)
         return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True, input_slope=0.2)  # fp32 NCHW logits

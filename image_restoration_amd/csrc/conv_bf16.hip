@@ -50,6 +50,7 @@ struct ConvParamsH {
   int src_shift;    // 1: nearest x2 upsample on the fly
   int mask_cbn;
   int out_u2;       // 1: the CB16 destination is written pixel-unshuffled (sr_conv3x3_desc.out_unshuffle2)
+  int res1_mode;    // bit 0: res1 is read pixel-unshuffled (res1_u2); bit 1: sign-keeping rounding of act + res1 (res1_keep_sign)
   float slope, alpha, beta1, beta2, mask_slope;
   long long* dbg;  // development: per-workgroup phase clocks
 };
@@ -142,7 +143,32 @@ __device__ __forceinline__ void epilogue_cb16(const ConvParamsH& p, f32x16 (&acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[q][e] += beta * bf2f(rr[q * 2 + (e >> 1)], e & 1);
         };
-        if (p.res1) add_res(p.res1, p.res1_nb, p.beta1);
+        if (p.res1 && p.res1_mode) {
+          // a skip connection that only exists pixel-unshuffled, added so that the stored sum still tells the activation's sign
+          // (sr_conv3x3_desc.res1_u2 / res1_keep_sign): the value is finished here, already rounded to bf16 (pass 2 converts exactly)
+          long long roff = off;
+          if (p.res1_mode & 1)
+            roff = (((long long)((((y & 1) << 1) | (x & 1)) * p.cout_blocks + cb) * (HW >> 2) + (long long)(y >> 1) * (p.W >> 1) + (x >> 1)) * 16 + h * 8) * 2;
+          u32x4 rr = *(const __attribute__((address_space(1))) u32x4*)(p.res1 + (long long)n * p.res1_nb + roff);
+          swap_halves(rr);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned w16 = (e & 1) ? (rr[q * 2 + (e >> 1)] >> 16) : (rr[q * 2 + (e >> 1)] & 0xffffu);
+              const float act = v[q][e];
+              float sum = act + p.beta1 * __builtin_bit_cast(float, w16 << 16);
+              if (p.res1_mode & 2) {
+                const __bf16 rb = (__bf16)sum;
+                unsigned sb = __builtin_bit_cast(unsigned short, rb);
+                if (act > 0.f && sb == w16) sb = (w16 & 0x7fffu) == 0 ? 1u : ((w16 & 0x8000u) ? w16 - 1 : w16 + 1);
+                sum = __builtin_bit_cast(float, sb << 16);
+              }
+              v[q][e] = sum;
+            }
+        } else if (p.res1) {
+          add_res(p.res1, p.res1_nb, p.beta1);
+        }
         if (p.res2) add_res(p.res2, p.res2_nb, p.beta2);
         if (p.mask && cb < p.mask_cbn) {
           u32x4 mm = *(const __attribute__((address_space(1))) u32x4*)(p.mask + (long long)n * p.mask_nb + off);
@@ -1808,6 +1834,11 @@ static int fill_params_h(const sr_conv3x3_desc* d, ConvParamsH& p, const char* w
   p.beta2 = d->beta2;
   p.dbg = nullptr;
   p.out_u2 = d->out_unshuffle2 ? 1 : 0;
+  p.res1_mode = (d->res1_u2 ? 1 : 0) | (d->res1_keep_sign ? 2 : 0);
+  SR_CHECK_ARG(!p.res1_mode || (d->res1 && !d->out_nchw && !d->out_unshuffle2 && d->cout % 16 == 0 && p.H % 2 == 0 && p.W % 2 == 0 &&
+                                (!d->res1_keep_sign || (d->beta1 == 1.f && d->alpha > 0.f && !d->res2 && !d->mask_src))),
+               "%s: res1_u2 / res1_keep_sign need res1, a plain CB16 destination of even size with cout %% 16 == 0 (keep_sign: beta1 = 1, "
+               "alpha > 0, no res2 / mask)", who);
   SR_CHECK_ARG(!p.out_u2 || (!d->out_nchw && d->cout % 16 == 0 && p.H % 2 == 0 && p.W % 2 == 0),
                "%s: out_unshuffle2 needs a CB16 destination, cout %% 16 == 0 and an even output size (%dx%d, cout %d)", who, p.H, p.W, d->cout);
   SR_CHECK_ARG((long long)p.H * p.W * 32 * (long long)(p.cout_blocks > p.cin_blocks ? p.cout_blocks : p.cin_blocks) < (1ll << 31),
@@ -1860,7 +1891,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   for (int k = 0; k < 5; ++k) {
     const sr_conv3x3_desc& c = d[k];
     if (c.in != d[0].in || c.in_img_stride != d[0].in_img_stride || c.n != n || c.in_h != h || c.in_w != w || c.upsample || c.out_nchw ||
-        c.s2_channels != 0 || c.out_unshuffle2 || c.cin_pad != 64 + 32 * k || c.cout != (k < 4 ? 32 : 64) || c.accumulate)
+        c.s2_channels != 0 || c.out_unshuffle2 || c.res1_u2 || c.res1_keep_sign || c.cin_pad != 64 + 32 * k || c.cout != (k < 4 ? 32 : 64) || c.accumulate)
       return SR_OK;
     if (k < 4 && ((const __bf16*)c.out != (const __bf16*)d[0].in + (64 + 32 * k) * hw || c.out_img_stride != d[0].in_img_stride ||
                   c.res1 || c.res2))
@@ -1992,7 +2023,7 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
                     !sr::prof_on();
   for (int k = 0; k < nconv && one_launch; ++k) {
     const sr_conv3x3_desc& c = d[k];
-    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 && !c.out_unshuffle2 &&
+    one_launch = c.n == d[0].n && c.in_h == d[0].in_h && c.in_w == d[0].in_w && !c.upsample && !c.out_nchw && c.s2_channels == 0 && !c.out_unshuffle2 && !c.res1_u2 && !c.res1_keep_sign &&
                  c.cout <= 64 && c.cin_pad <= 256 && c.in_h % rows == 0;
   }
   const int conc = sr::launch_concurrency();
@@ -2092,7 +2123,7 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
     const int naux = (d->res1 ? 1 : 0) + (d->res2 ? 1 : 0) + (d->mask_src ? 1 : 0);
     int dev = 0, cus = 0;
     if (naux <= 1 && !(naux == 1 && p.cin_blocks == 2) /* that instance spills */ && (!d->mask_src || d->mask_cbn >= 4) &&
-        (!p.out_u2 || (naux == 0 && p.cin_blocks == 1)) && hipGetDevice(&dev) == hipSuccess &&
+        (!p.out_u2 || (naux == 0 && p.cin_blocks == 1)) && !p.res1_mode && hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
       const int conc0 = sr::launch_concurrency();
       const int grid = cus / (conc0 > 1 ? conc0 : 1);

@@ -798,7 +798,7 @@ extern "C" int sr_conv3x3_chain_f32(const sr_conv3x3_desc* d, int nconv, int32_t
 }
 
 extern "C" int sr_conv3x3_f32(const sr_conv3x3_desc* d, void* stream_) {
-  SR_CHECK_ARG(!d || !d->out_unshuffle2, "sr_conv3x3_f32: out_unshuffle2 is an option of sr_conv3x3_bf16");
+  SR_CHECK_ARG(!d || !(d->out_unshuffle2 || d->res1_u2 || d->res1_keep_sign), "sr_conv3x3_f32: out_unshuffle2 / res1_u2 / res1_keep_sign are options of sr_conv3x3_bf16");
   hipStream_t stream = (hipStream_t)stream_;
   ConvParams p;
   int rc = fill_common(d, &p, "sr_conv3x3_f32");

@@ -130,6 +130,28 @@ __global__ void add16_u2_kernel(const __bf16* __restrict__ a, const __bf16* __re
   *(bf16x8_t*)(out + i * 8) = o;
 }
 
+// dz = gy * (xsum - x0 > 0 ? 1 : slope) with x0 pixel-unshuffled: LeakyReLU backward of a conv stored as act + x0 (res1_keep_sign)
+__global__ void lrelu_bwd_diff16_u2_kernel(const __bf16* __restrict__ gy, const __bf16* __restrict__ xsum, const __bf16* __restrict__ x0_u2,
+                                           __bf16* __restrict__ dz, float slope, int cblocks, int h, int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = (int)(i & 1);
+  long long r = i >> 1;
+  const int X = (int)(r % (2 * w));
+  r /= 2 * w;
+  const int Y = (int)(r % (2 * h));
+  r /= 2 * h;
+  const int cb = (int)(r % cblocks);
+  const long long n = r / cblocks;
+  const int par = (Y & 1) * 2 + (X & 1);
+  const long long small = (((n * 4 * cblocks + (long long)par * cblocks + cb) * h + (Y >> 1)) * w + (X >> 1)) * 16 + half * 8;
+  const bf16x8_t g = *(const bf16x8_t*)(gy + i * 8), s = *(const bf16x8_t*)(xsum + i * 8), x0 = *(const bf16x8_t*)(x0_u2 + small);
+  bf16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = ((float)s[e] - (float)x0[e] > 0.f) ? g[e] : (__bf16)((float)g[e] * slope);
+  *(bf16x8_t*)(dz + i * 8) = o;
+}
+
 // y = x > 0 ? x : slope * x, 8 elements per thread (a stand-alone ReLU after a feature that is wanted before it)
 __global__ void lrelu_fwd16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, float slope, long long n8) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,6 +496,17 @@ extern "C" int sr_cb16_fork_bwd_u2_bf16(const void* g_skip, const void* g_u, con
   hipLaunchKernelGGL(fork_bwd16_kernel<true>, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)g_skip, (const __bf16*)g_u,
                      (const __bf16*)mask_u2, (__bf16*)dz, slope, cblocks, h, w, total);
   SR_CHECK_LAUNCH("fork_bwd16 (u2 mask)");
+  return SR_OK;
+}
+
+extern "C" int sr_lrelu_bwd_diff_u2_bf16(const void* gy, const void* xsum, const void* x0_u2, void* dz, float slope, int n, int cblocks,
+                                         int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(gy && xsum && x0_u2 && dz && n > 0 && cblocks > 0 && h > 0 && w > 0, "sr_lrelu_bwd_diff_u2_bf16: bad argument");
+  const long long total = (long long)n * cblocks * 4 * h * w * 2;
+  hipLaunchKernelGGL(lrelu_bwd_diff16_u2_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const __bf16*)gy, (const __bf16*)xsum,
+                     (const __bf16*)x0_u2, (__bf16*)dz, slope, cblocks, h, w, total);
+  SR_CHECK_LAUNCH("lrelu_bwd_diff16_u2");
   return SR_OK;
 }
 

@@ -86,12 +86,17 @@ class ConvFn16(torch.autograd.Function):
       out_unshuffled   the output is stored pixel-unshuffled ONLY ([N, 4C/16, H/2, W/2, 16]: what the next 4x4/s2 conv reads;
                        sr_conv3x3_desc.out_unshuffle2) and handed to ForkU2Fn16.  Convention for such tensors: their GRADIENT
                        travels in the plain layout ([N, C/16, H, W, 16] bytes) under the unshuffled shape — same element count, and
-                       every producer / consumer of it is one of this module's functions.
+                       every producer / consumer of it is one of this module's functions;
+      skip_u2          a skip connection that only exists pixel-unshuffled (ForkU2Fn16's handle) is added to the activation in the
+                       conv's epilogue: out = LeakyReLU(conv) + skip, stored with the sign-keeping rounding of
+                       sr_conv3x3_desc.res1_keep_sign, so neither the activation nor a separate sum pass exists; the backward
+                       recovers the LeakyReLU mask from (out, skip) exactly (sr_lrelu_bwd_diff_u2_bf16) and hands the skip the
+                       plain gradient (under the unshuffled shape, as above).
     """
 
     @staticmethod
     def forward(ctx, x, weight, bias, act_slope, out_nchw, pre_unshuffled=False, input_slope=1.0, grad_premasked=False,
-                out_unshuffled=False):
+                out_unshuffled=False, skip_u2=None):
         k = weight.size(2)
         weight = weight.detach().contiguous().float()
         cout, cin = weight.shape[:2]
@@ -110,12 +115,19 @@ class ConvFn16(torch.autograd.Function):
             H.conv3x3_bf16(src, pc, out_nchw=y)
             saved_y = None
             ret = y
+        elif skip_u2 is not None:
+            assert k == 3 and act_slope != 1.0 and not grad_premasked and not out_unshuffled
+            skip_u2 = skip_u2.contiguous()
+            assert skip_u2.shape == (src.n, 4 * cout // 16, src.h // 2, src.w // 2, 16), (tuple(skip_u2.shape), src.n, cout, src.h, src.w)
+            out = H.conv3x3_bf16(src, pc, act_slope=act_slope, res1=_cb16(skip_u2), beta1=1.0, res1_u2=True, res1_keep_sign=True)
+            saved_y = out.buf     # = activation + skip: the mask is sign(saved_y - skip)
+            ret = out.buf
         else:
             out = H.conv3x3_bf16(src, pc, act_slope=act_slope, s2_channels=s2, out_unshuffle2=out_unshuffled)
             assert not out_unshuffled or grad_premasked, 'the fork applies the LeakyReLU derivative of an unshuffled output'
             saved_y = out.buf if (act_slope != 1.0 and not grad_premasked) else None
             ret = out.buf
-        ctx.save_for_backward(src.buf, w3, saved_y)
+        ctx.save_for_backward(src.buf, w3, saved_y, skip_u2 if (skip_u2 is not None and not out_nchw) else None)
         ctx.act_slope, ctx.has_bias, ctx.k, ctx.out_nchw = act_slope, bias is not None, k, out_nchw
         ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
         ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked, ctx.s2 = pre_unshuffled, input_slope, grad_premasked, s2
@@ -126,7 +138,7 @@ class ConvFn16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
-        xs, w3, y = ctx.saved_tensors
+        xs, w3, y, skip_u2 = ctx.saved_tensors
         src = _cb16(xs)
         dev = gy.device
         cout, cin3 = w3.shape[:2]
@@ -137,7 +149,13 @@ class ConvFn16(torch.autograd.Function):
             if ctx.out_unshuffled:  # plain-layout gradient under the unshuffled shape (see the class docstring)
                 n_, cb4, hh, ww, _ = gy.shape
                 gy = gy.view(n_, cb4 // 4, 2 * hh, 2 * ww, 16)
-            if y is not None and not ctx.grad_premasked:
+            if skip_u2 is not None:     # y = activation + skip (sign-keeping rounding): mask = sign(y - skip)
+                dz = torch.empty_like(gy)
+                n_, cb_, h2_, w2_, _ = gy.shape
+                with torch.cuda.device(dev):
+                    _lib.check(lib.sr_lrelu_bwd_diff_u2_bf16(gy.data_ptr(), y.data_ptr(), skip_u2.data_ptr(), dz.data_ptr(), ctx.act_slope,
+                                                             n_, cb_, h2_ // 2, w2_ // 2, _stream(dev)), 'sr_lrelu_bwd_diff_u2_bf16')
+            elif y is not None and not ctx.grad_premasked:
                 dz = torch.empty_like(gy)
                 with torch.cuda.device(dev):
                     _lib.check(lib.sr_lrelu_bwd_bf16(gy.data_ptr(), y.data_ptr(), dz.data_ptr(), ctx.act_slope, gy.numel(),
@@ -159,7 +177,8 @@ class ConvFn16(torch.autograd.Function):
             dw, db = H.conv3x3_wgrad_bf16(src, dzc, cout, cin3, want_bias=ctx.has_bias)
             if ctx.k == 4:
                 dw = _dw3_to_dw4(dw, ctx.cout, ctx.cin)
-        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None, None
+        g_skip = gy.view(skip_u2.shape) if (skip_u2 is not None and ctx.needs_input_grad[9]) else None  # plain layout, unshuffled shape
+        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None, None, g_skip
 
 
 class SkipForkFn16(torch.autograd.Function):

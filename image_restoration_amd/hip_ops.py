@@ -406,7 +406,8 @@ class PackedConvBF16:
 
 
 def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1.0, res1=None, beta1=0.0, res2=None,
-                    beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0, out_unshuffle2=False):
+                    beta2=0.0, out_nchw=None, mask=None, mask_slope=0.2, s2_channels=0, s2_side=0, out_unshuffle2=False,
+                    res1_u2=False, res1_keep_sign=False):
     assert src.channels == pc.src_channels, (src.channels, pc.src_channels)
     H, W = (2 * src.h, 2 * src.w) if upsample else (src.h, src.w)
     d = _lib.ConvDesc()
@@ -433,6 +434,7 @@ def _conv_desc_bf16(src, pc, out=None, *, upsample=False, act_slope=1.0, alpha=1
     d.n, d.act_slope, d.alpha = src.n, act_slope, alpha
     if res1 is not None:
         d.res1, d.res1_img_stride, d.beta1 = res1.ptr, res1.img_stride, beta1
+        d.res1_u2, d.res1_keep_sign = int(res1_u2), int(res1_keep_sign)
     if res2 is not None:
         d.res2, d.res2_img_stride, d.beta2 = res2.ptr, res2.img_stride, beta2
     if mask is not None:

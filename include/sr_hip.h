@@ -127,6 +127,14 @@ typedef struct sr_conv3x3_desc {
                              [y / 2][x / 2][16] with ry = y & 1, rx = x & 1, CB = cout / 16 (cout % 16 == 0, even output H and W): the layout
                              sr_cb16_unshuffle2_bf16 produces and the next 4x4 / stride-2 conv of a U-Net encoder reads, so the activation
                              is never stored in the plain layout at all (the *_u2 entry points below read it where it is) */
+  int res1_u2;            /* sr_conv3x3_bf16 only.  1: res1 only exists pixel-unshuffled (an out_unshuffle2 tensor of the output's size and
+                             channel count) and is read where it is */
+  int res1_keep_sign;     /* sr_conv3x3_bf16 only; needs res1, beta1 = 1, alpha > 0, no res2 / mask.  1: out = bf16(act(conv + bias) + res1)
+                             is rounded so that sign(out - res1) == sign(conv + bias): where the activation is positive but the sum
+                             would round to res1 itself, the next bf16 above res1 is stored (<= 1 ulp, the size of the rounding).
+                             A skip connection added in the epilogue then still carries the LeakyReLU mask of the conv:
+                             sr_lrelu_bwd_diff_u2_bf16 recovers it exactly from (out, res1) and neither the activation nor a
+                             separate sum is ever stored (UNetDiscriminatorSN: conv6 + x0) */
 } sr_conv3x3_desc;
 
 /* Fused 3x3 / stride 1 / pad 1 convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -455,6 +463,10 @@ int sr_bilinear2x_fwd_u2_bf16(const void* src, int64_t src_img_stride, const voi
                               int64_t dst_img_stride, int n, int cblocks, int h, int w, void* stream);
 int sr_cb16_fork_bwd_u2_bf16(const void* g_skip, const void* g_u, const void* mask_u2, void* dz, float slope, int n, int cblocks, int h,
                              int w, void* stream);
+/* dz = gy * (xsum - x0 > 0 ? 1 : slope): LeakyReLU backward of a conv whose output was stored as xsum = act + x0 with
+ * res1_keep_sign; xsum, gy, dz plain [n][cblocks][2h][2w][16], x0_u2 pixel-unshuffled [n][4 cblocks][h][w][16]. */
+int sr_lrelu_bwd_diff_u2_bf16(const void* gy, const void* xsum, const void* x0_u2, void* dz, float slope, int n, int cblocks, int h,
+                              int w, void* stream);
 /* nn.BatchNorm2d + LeakyReLU of VGGStyleDiscriminator128 on CB16 activations (bf16 in / out; statistics, running
  * buffers, gamma / beta and their gradients fp32): twins of sr_bn_lrelu_{fwd,bwd}_f32, same arguments. */
 int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_img_stride, void* y, int64_t y_img_stride, int n, int c, int h, int w,

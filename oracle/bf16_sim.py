@@ -72,9 +72,9 @@ def unet_forward_bf16_storage(x, w, skip_connection=True):
     x3 = r(lr(cv(x2, 'conv3', 2)))
     x4 = r(lr(cv(up(x3), 'conv4')))
     x5 = r(lr(cv(up(r(x4 + x2) if skip_connection else x4), 'conv5')))
-    x6 = r(lr(cv(up(r(x5 + x1) if skip_connection else x5), 'conv6')))
-    if skip_connection:
-        x6 = r(x6 + x0)
+    # (round 3: conv6 adds x0 in its epilogue — the activation itself is never stored, the sum is rounded once)
+    x6 = lr(cv(up(r(x5 + x1) if skip_connection else x5), 'conv6'))
+    x6 = r(x6 + x0) if skip_connection else r(x6)
     out = r(lr(cv(x6, 'conv7')))
     out = r(lr(cv(out, 'conv8')))
     return cv(out, 'conv9')

@@ -372,3 +372,53 @@ def test_readers_of_unshuffled_only_activations_equal_their_plain_forms(cuda):
     xs, xu = B.SkipForkFn16.apply(xr, 0.2)
     torch.autograd.backward([xs, xu], [g_skip, g_u])
     assert torch.equal(u.grad.view(x.shape), xr.grad)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 64, 32, 48), (4, 128, 64, 64, 96), (1, 32, 32, 10, 14)])
+def test_skip_added_in_the_conv_epilogue_keeps_the_activation_sign_recoverable(cuda, n, cin, cout, h, w):
+    """sr_conv3x3_desc.res1_u2 + res1_keep_sign: out = bf16(LeakyReLU(conv) + x0) with x0 read from its pixel-unshuffled form and the
+    rounding nudged by at most one bf16 ulp so that sign(out - x0) == sign(conv) for EVERY element — checked against the separately
+    computed activation — which is what lets sr_lrelu_bwd_diff_u2_bf16 replace the stored activation in the backward (bit-identical
+    to sr_lrelu_bwd_bf16 on the real activation).  The skip is made much larger than the activation so that absorbed sums are common."""
+    import ctypes as C
+    from image_restoration_amd import _lib
+    g = torch.Generator().manual_seed(cin + h)
+    x = H.CB16(torch.randn(n, cin // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda))
+    pc = H.PackedConvBF16((torch.randn(cout, cin, 3, 3, generator=g) * 0.01).to(cuda), None)
+    x0 = (torch.randn(n, cout // 16, h, w, 16, generator=g) * 40).to(torch.bfloat16).to(cuda)
+    x0[0, 0, :2] = 0.0                                        # zeros (both signs) among the skip values
+    x0[0, 0, 1] = -0.0
+    x0u = B._unshuffle2(x0)
+    act = H.conv3x3_bf16(x, pc, act_slope=0.2).buf            # the activation, stored on its own (what the fused form never stores)
+    out = H.conv3x3_bf16(x, pc, act_slope=0.2, res1=H.CB16(x0u), beta1=1.0, res1_u2=True, res1_keep_sign=True).buf
+    plain = H.conv3x3_bf16(x, pc, act_slope=0.2, res1=H.CB16(x0), beta1=1.0).buf          # ordinary rounding of the same sum
+    diff = out.float() - x0.float()
+    # (the bf16-stored activation has the sign of the fp32 one except where it rounded to zero: compare where it is non-zero)
+    nz = act.float() != 0
+    assert torch.equal((diff > 0)[nz], (act.float() > 0)[nz])
+    assert not bool(((diff > 0) & (act.float() < 0)).any())
+    changed = out != plain
+    assert 0 < int(changed.sum()) < 0.5 * out.numel()         # the nudge is exercised, and it is the exception
+    one_ulp = (out.view(torch.int16).int() - plain.view(torch.int16).int()).abs() <= 1
+    assert bool(one_ulp[changed].all()) and bool((plain == x0)[changed].all())
+    # backward mask from (out, x0_u2) == mask from the activation
+    gy = torch.randn(n, cout // 16, h, w, 16, generator=g).to(torch.bfloat16).to(cuda)
+    lib = _lib.load()
+    dz = torch.empty_like(gy)
+    _lib.check(lib.sr_lrelu_bwd_diff_u2_bf16(gy.data_ptr(), out.data_ptr(), x0u.data_ptr(), dz.data_ptr(), 0.2, n, cout // 16, h // 2, w // 2,
+                                             None), 'sr_lrelu_bwd_diff_u2_bf16')
+    want = torch.where(diff > 0, gy, (gy.float() * 0.2).to(torch.bfloat16))
+    assert torch.equal(dz, want)
+    # autograd wiring: ConvFn16(skip_u2=...) against conv -> AddFn16 with the same weights
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(cuda).requires_grad_(True)
+    xin = x.buf.clone().requires_grad_(True)
+    sk = x0u.clone().requires_grad_(True)
+    y1 = B.ConvFn16.apply(xin, wt, None, 0.2, False, False, 1.0, False, False, sk)
+    y1.backward(gy)
+    wt2, xin2, sk2 = wt.detach().clone().requires_grad_(True), x.buf.clone().requires_grad_(True), x0u.clone().requires_grad_(True)
+    y2 = B.AddFn16.apply(B.ConvFn16.apply(xin2, wt2, None, 0.2, False), sk2, True)
+    y2.backward(gy)
+    assert float((y1.float() - y2.float()).abs().max()) <= float(y2.float().abs().max()) * 2 ** -7
+    assert torch.equal(sk.grad, sk2.grad)
+    for a_, b_ in ((wt.grad, wt2.grad), (xin.grad.float(), xin2.grad.float())):
+        assert float((a_ - b_).norm()) <= 2e-2 * float(b_.norm()) + 1e-6   # masks differ only where the activation is within rounding of 0
