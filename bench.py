@@ -306,11 +306,11 @@ def measure_tiled(net, world, rank, dev, dist, backend, *, dtype, steps, warmup,
         'lr_megapixels_per_sec': round(steps * H * W / dt / 1e6, 3)}
     if profile and world == 1:
         peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
-        quarter = img[:, :, :1024, :1024 * tile_batch // 2].contiguous()  # tile_batch whole 512x512 cells: the frame's launch shapes
+        quarter = img[:, :, :1024, :min(W, 512 * max(2, tile_batch // 2))].contiguous()  # whole 512x512 cells of the frame: its launch shapes
         ks = profile_launches(lambda: tiled_forward(net, quarter, tile=512, pad=16, scale=4, max_batch=tile_batch, out_dtype=torch.uint8), peak)
         torch.cuda.synchronize()
         res['roofline'] = roofline_of(ks, peak, '_tiled')  # no stored counters at the tiler's launch sizes: traffic null
-        res['roofline']['note'] = 'kernel table from a %dx%d corner of the frame (%d full cells per forward, the launch shapes of the frame)' \
+        res['roofline']['note'] = 'kernel table from a %dx%d corner of the frame (whole cells, at most %d per forward: the launch shapes of the frame)' \
             % (quarter.shape[2], quarter.shape[3], tile_batch)
     del out
     torch.cuda.empty_cache()
@@ -376,7 +376,7 @@ def main():
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help="fp32 = the BASELINE metric (default, the judged line); bf16 = secondary reduced-precision run")
     ap.add_argument('--groups', type=int, default=0, help='override sr_set_forward_groups (tuning; 0 = library default)')
-    ap.add_argument('--tile-batch', type=int, default=4, help='--mode tiled: cells per forward')
+    ap.add_argument('--tile-batch', type=int, default=8, help='--mode tiled: most cells per forward (tiled_forward\'s own default; equal-shape cells are dealt out in equal shares)')
     ap.add_argument('--mode', choices=('infer', 'train', 'tiled'), default='infer',
                     help='infer = the BASELINE metric (default, the judged line); train = secondary line: full ESRGAN '
                          'optimize_parameters steps (BASELINE configs 3-4), data-parallel over the ranks; tiled = secondary line: '
