@@ -249,6 +249,14 @@ bool WgradLane::begin(hipStream_t caller, bool enable) {
   return true;
 }
 }  // namespace sr
+namespace {
+int g_bn_small = 1;
+}
+namespace sr {
+bool bn_small_enabled() { return g_bn_small != 0; }
+}
+// Development switch (A/B, tests; not part of the ABI): 0 = BatchNorm of small tensors on the general multi-launch path.
+extern "C" void sr_dev_set_bn_small(int on) { g_bn_small = on; }
 // Development switch (not part of the ABI): -1 = automatic, 0 = weight gradients on the caller's stream, 1 = always on the lane.
 extern "C" void sr_dev_set_backward_overlap(int mode) { g_backward_overlap = mode; }
 

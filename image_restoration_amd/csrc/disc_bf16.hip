@@ -11,6 +11,7 @@
 // 36 taps are live, a 2.25x MAC overhead that is free at bf16 rates (these layers are memory-bound), against four
 // accumulating parity passes with bf16 rounding in between.
 #include "sr_internal.h"
+#include "bn_small.h"
 
 namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -755,6 +756,28 @@ extern "C" int sr_bn_lrelu_fwd_bf16(const void* x, int64_t x_ns, void* y, int64_
   SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_fwd_bf16: workspace too small");
   const int cblocks = (c + 15) / 16, hw = h * w;
   const long long count = (long long)n * hw;
+  if (train && count <= bnsmall::kBnSmallPixels && sr::bn_small_enabled()) {  // one launch for the whole pass (bn_small.h)
+    bnsmall::Params<__bf16> q = {};
+    q.x = (const __bf16*)x;
+    q.out = (__bf16*)y;
+    q.x_ns = x_ns;
+    q.out_ns = y_ns;
+    q.n = n;
+    q.c = c;
+    q.hw = hw;
+    q.gamma = gamma;
+    q.beta = beta;
+    q.mean = save_mean;
+    q.invstd = save_invstd;
+    q.running_mean = running_mean;
+    q.running_var = running_var;
+    q.momentum = momentum;
+    q.eps = eps;
+    q.slope = slope;
+    bnsmall::launch<__bf16, 16, false>(q, stream);
+    SR_CHECK_LAUNCH("bn_small fwd16");
+    return SR_OK;
+  }
   float* part = (float*)ws;
   if (train) {
     BnRed16 p = {};
@@ -794,6 +817,29 @@ extern "C" int sr_bn_lrelu_bwd_bf16(const void* x, int64_t x_ns, const void* dy,
   SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_bwd_bf16: workspace too small");
   const int cblocks = (c + 15) / 16, hw = h * w;
   const long long count = (long long)n * hw;
+  if (train && count <= bnsmall::kBnSmallPixels && sr::bn_small_enabled()) {
+    bnsmall::Params<__bf16> q = {};
+    q.x = (const __bf16*)x;
+    q.dy = (const __bf16*)dy;
+    q.y = (const __bf16*)y;
+    q.out = (__bf16*)dx;
+    q.x_ns = x_ns;
+    q.dy_ns = dy_ns;
+    q.y_ns = y_ns;
+    q.out_ns = dx_ns;
+    q.n = n;
+    q.c = c;
+    q.hw = hw;
+    q.gamma = gamma;
+    q.mean = (float*)save_mean;
+    q.invstd = (float*)save_invstd;
+    q.dgamma = dgamma;
+    q.dbeta = dbeta;
+    q.slope = slope;
+    bnsmall::launch<__bf16, 16, true>(q, stream);
+    SR_CHECK_LAUNCH("bn_small bwd16");
+    return SR_OK;
+  }
   float* part = (float*)ws;
   BnRed16 p = {};
   p.x = (const __bf16*)x;

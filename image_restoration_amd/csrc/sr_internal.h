@@ -131,6 +131,7 @@ struct WgradLane {
   }
   ~WgradLane() { end(); }  // error returns included: the caller's stream never runs ahead of work the lane still holds
 };
+bool bn_small_enabled();  // capi.hip: sr_dev_set_bn_small (development switch; default on)
 int backward_overlap();  // sr_dev_set_backward_overlap: -1 automatic (small launches only), 0 never, 1 always
 
 #define SR_CHECK_ARG(cond, ...)            \

@@ -5,6 +5,7 @@
 //   EMA (base_model.py:50-57).
 // All reductions are two-stage and deterministic (fixed grid, fixed summation order); no atomics.
 #include "sr_internal.h"
+#include "bn_small.h"
 
 namespace {
 
@@ -663,6 +664,28 @@ extern "C" int sr_bn_lrelu_fwd_f32(const float* x, int64_t x_ns, float* y, int64
   SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_fwd_f32: workspace too small");
   const int cblocks = (c + 7) / 8, hw = h * w;
   const long long count = (long long)n * hw;
+  if (train && count <= bnsmall::kBnSmallPixels && sr::bn_small_enabled()) {  // one launch for the whole pass (bn_small.h)
+    bnsmall::Params<float> q = {};
+    q.x = x;
+    q.out = y;
+    q.x_ns = x_ns;
+    q.out_ns = y_ns;
+    q.n = n;
+    q.c = c;
+    q.hw = hw;
+    q.gamma = gamma;
+    q.beta = beta;
+    q.mean = save_mean;
+    q.invstd = save_invstd;
+    q.running_mean = running_mean;
+    q.running_var = running_var;
+    q.momentum = momentum;
+    q.eps = eps;
+    q.slope = slope;
+    bnsmall::launch<float, 8, false>(q, stream);
+    SR_CHECK_LAUNCH("bn_small fwd");
+    return SR_OK;
+  }
   float* part = (float*)ws;
   if (train) {
     BnRedParams p = {};
@@ -701,6 +724,29 @@ extern "C" int sr_bn_lrelu_bwd_f32(const float* x, int64_t x_ns, const float* dy
   SR_CHECK_ARG(ws_bytes >= sr_reduce_workspace_bytes(c), "sr_bn_lrelu_bwd_f32: workspace too small");
   const int cblocks = (c + 7) / 8, hw = h * w;
   const long long count = (long long)n * hw;
+  if (train && count <= bnsmall::kBnSmallPixels && sr::bn_small_enabled()) {
+    bnsmall::Params<float> q = {};
+    q.x = x;
+    q.dy = dy;
+    q.y = y;
+    q.out = dx;
+    q.x_ns = x_ns;
+    q.dy_ns = dy_ns;
+    q.y_ns = y_ns;
+    q.out_ns = dx_ns;
+    q.n = n;
+    q.c = c;
+    q.hw = hw;
+    q.gamma = gamma;
+    q.mean = (float*)save_mean;
+    q.invstd = (float*)save_invstd;
+    q.dgamma = dgamma;
+    q.dbeta = dbeta;
+    q.slope = slope;
+    bnsmall::launch<float, 8, true>(q, stream);
+    SR_CHECK_LAUNCH("bn_small bwd");
+    return SR_OK;
+  }
   float* part = (float*)ws;
   BnRedParams p = {};
   p.x = x;
