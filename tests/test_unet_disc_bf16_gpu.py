@@ -165,14 +165,14 @@ def test_conv_chain_with_epilogue_masks_matches_separate_passes(cuda):
         assert float(d.max()) <= 2 ** -6 * float(u.float().abs().max()) and float(d.norm() / u.float().norm()) < 4e-3
 
 
-@pytest.mark.parametrize('nf,h,w', [(16, 32, 48), (64, 64, 64)])
-def test_unet_bf16_vs_fp32_path(cuda, nf, h, w):
+@pytest.mark.parametrize('nf,h,w,skip', [(16, 32, 48, True), (64, 64, 64, True), (32, 40, 24, False)])
+def test_unet_bf16_vs_fp32_path(cuda, nf, h, w, skip):
     """Logits and parameter gradients of the bf16 network against the fp32 HIP network (itself checked against the oracle in
     tests/test_unet_disc_gpu.py) on the same weights: logits within 3 % of their range, every gradient within relative-L2
     8e-2 and cosine >= 0.995 (10 layers of bf16 activations and activation gradients)."""
     torch.manual_seed(7)
-    d32 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=True)).to(cuda).train()
-    d16 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=True,
+    d32 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=skip)).to(cuda).train()
+    d16 = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=nf, skip_connection=skip,
                                  compute_dtype='bf16')).to(cuda).train()
     d16.load_state_dict(d32.state_dict())
     x = torch.rand(2, 3, h, w, device=cuda)
