@@ -192,7 +192,10 @@ def test_unet_bf16_vs_fp32_path(cuda, nf, h, w, skip):
         assert torch.isfinite(b).all(), name
         rel = float((a - b).norm() / (a.norm() + 1e-20))
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-20))
-        assert rel <= 8e-2 and cos >= 0.995, (name, rel, cos)
+        # without skip connections every gradient funnels through the 512-channel bottleneck (5 x 3 pixels here) and bf16 storage noise
+        # is 2-3x larger (measured 0.17 / 0.985 on the input gradient) — the same network agrees with the float64 model of bf16
+        # storage to 1.2e-2 (next test), so the wider bound is about bf16, not about the kernels
+        assert (rel <= 8e-2 and cos >= 0.995) if skip else (rel <= 0.3 and cos >= 0.96), (name, rel, cos)
     # power-iteration buffers advanced identically (spectral norm stays fp32)
     assert torch.allclose(d16.conv3.weight_u, d32.conv3.weight_u, atol=1e-6)
 
@@ -287,14 +290,15 @@ def test_c3_training_config_runs_all_bf16(cuda):
     assert not torch.equal(model.net_g_ema.conv_last.weight, w0)
 
 
-def test_unet_bf16_equals_a_float64_model_of_bf16_storage(cuda):
+@pytest.mark.parametrize('skip', [True, False])
+def test_unet_bf16_equals_a_float64_model_of_bf16_storage(cuda, skip):
     """The bf16 U-Net (fused fork / add-bilinear / epilogue-mask passes) against oracle/bf16_sim.py — float64 arithmetic with a
     bf16 round trip wherever the HIP path stores a tensor — on the effective (spectrally normalised) weights, eval mode:
     logits to 5e-3 relative L2, input gradient and the gradients of the plain parameters (conv0, conv9) to 3e-2; against the
     fp32 path the same quantities differ by 2-8 % (test above)."""
     from oracle.bf16_sim import unet_forward_bf16_storage
     torch.manual_seed(11)
-    net = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=16, skip_connection=True, compute_dtype='bf16')).to(cuda)
+    net = ira.build_network(dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=16, skip_connection=skip, compute_dtype='bf16')).to(cuda)
     with torch.no_grad():
         for _ in range(12):  # let the power iterations settle so that the normalised weights (and logits) are O(1)
             net(torch.rand(1, 3, 16, 16, device=cuda))
@@ -308,7 +312,7 @@ def test_unet_bf16_equals_a_float64_model_of_bf16_storage(cuda):
             w[f'conv{i}.bias'] = conv.bias.detach().cpu().double().requires_grad_(True)
     x = torch.rand(2, 3, 48, 64)
     xr = x.double().requires_grad_(True)
-    yr = unet_forward_bf16_storage(xr, w)
+    yr = unet_forward_bf16_storage(xr, w, skip_connection=skip)
     R = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1))
     (yr * R.double()).sum().backward()
     xc = x.to(cuda).requires_grad_(True)
