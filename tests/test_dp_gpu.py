@@ -73,3 +73,18 @@ def test_two_ranks_at_batch_b_equal_one_rank_at_batch_2b(cuda, tmp_path):
         mine, theirs = model.optimizer_g.flat_p.cpu().numpy().astype(np.float64), r0[f'it{it}_g_params'].astype(np.float64)
         assert np.linalg.norm(mine - theirs) <= 1e-3 * np.linalg.norm(theirs), it
     assert abs(model.get_current_log()['l_pix'] - float(r0['logs'][-1][list(r0['log_keys']).index('l_pix')])) < 1e-3
+
+
+def test_collectives_of_the_path_run_through_rccl_on_device_tensors(cuda, tmp_path):
+    """backend 'nccl' = RCCL: one rank (a one-GPU box cannot host two RCCL ranks) runs data-parallel ESRGAN steps — arena all-reduce,
+    loss reduce, replica broadcast — and the tiler's gather on DEVICE tensors through the RCCL communicator; parameters after two
+    steps equal a single-process run bit for bit (the mean over one rank is the identity)."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(29900 + os.getpid() % 90), os.path.join(ROOT, 'tests', 'helpers', 'rccl_one_rank_worker.py'),
+                        '--out', str(tmp_path)], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.load(open(tmp_path / 'rccl_one_rank.json'))
+    assert out['backend'] == 'nccl' and out['params_equal_single_process'] and out['gather_equal']
+    assert all(v == v for v in out['log'].values())
