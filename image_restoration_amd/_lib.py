@@ -42,6 +42,12 @@ class WgradDesc(C.Structure):
     ]
 
 
+class SnLayer(C.Structure):
+    """struct sr_sn_layer (include/sr_hip.h)."""
+    _fields_ = [('w_orig', C.c_void_p), ('u', C.c_void_p), ('v', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int),
+                ('w_sn', C.c_void_p), ('sigma', C.c_void_p)]
+
+
 class RRDBNetCfg(C.Structure):
     """struct sr_rrdbnet_cfg (include/sr_hip.h)."""
     _fields_ = [('num_in_ch', C.c_int), ('num_out_ch', C.c_int), ('scale', C.c_int), ('num_feat', C.c_int),
@@ -93,6 +99,7 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_spectral_norm_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sr_spectral_norm_fwd_batch_f32': (C.c_int, [C.POINTER(SnLayer), C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sr_add_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'sr_gram_fwd_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     'sr_gram_bwd_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),

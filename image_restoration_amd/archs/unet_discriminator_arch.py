@@ -69,31 +69,43 @@ class UNetDiscriminatorSN(nn.Module):
         self.conv8 = SNConvParams(nf, nf, 3)
         self.conv9 = Conv3x3Params(nf, 1, bias=True)
 
+    def _sn_weights(self):
+        """The normalised weights of conv1..conv8 for this forward: one power iteration each in train mode, all eight layers in one
+        call (five launches instead of forty).  Returns {layer index: weight}."""
+        layers = [getattr(self, f'conv{i}') for i in range(1, 9)]
+        flat = []
+        for m in layers:
+            flat += [m.weight_orig, m.weight_u, m.weight_v]
+        eps = layers[0].eps
+        outs = A.SpectralNormBatchFn.apply(self.training, eps, *flat)
+        return {i + 1: w for i, w in enumerate(outs)}
+
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.SrHipError('UNetDiscriminatorSN.forward runs only on a HIP device (no CPU fallback)')
         assert x.size(2) % 8 == 0 and x.size(3) % 8 == 0, f'input {tuple(x.shape)} must be a multiple of 8 in H and W'
         if self.compute_dtype == 'bf16':
             return self._forward_bf16(x)
+        sn = self._sn_weights()
         conv = A.ConvFn.apply
         x0 = conv(A.ToCB8.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
-        x1 = conv(x0, self.conv1.weight(), None, 0.2)
-        x2 = conv(x1, self.conv2.weight(), None, 0.2)
-        x3 = conv(x2, self.conv3.weight(), None, 0.2)
+        x1 = conv(x0, sn[1], None, 0.2)
+        x2 = conv(x1, sn[2], None, 0.2)
+        x3 = conv(x2, sn[3], None, 0.2)
         x3 = A.Bilinear2xFn.apply(x3)
-        x4 = conv(x3, self.conv4.weight(), None, 0.2)
+        x4 = conv(x3, sn[4], None, 0.2)
         if self.skip_connection:
             x4 = A.AddFn.apply(x4, x2)
         x4 = A.Bilinear2xFn.apply(x4)
-        x5 = conv(x4, self.conv5.weight(), None, 0.2)
+        x5 = conv(x4, sn[5], None, 0.2)
         if self.skip_connection:
             x5 = A.AddFn.apply(x5, x1)
         x5 = A.Bilinear2xFn.apply(x5)
-        x6 = conv(x5, self.conv6.weight(), None, 0.2)
+        x6 = conv(x5, sn[6], None, 0.2)
         if self.skip_connection:
             x6 = A.AddFn.apply(x6, x0)
-        out = conv(x6, self.conv7.weight(), None, 0.2)
-        out = conv(out, self.conv8.weight(), None, 0.2)
+        out = conv(x6, sn[7], None, 0.2)
+        out = conv(out, sn[8], None, 0.2)
         out = conv(out, self.conv9.weight, self.conv9.bias, 1.0)
         return A.FromCB8.apply(out, 1)
 
@@ -104,6 +116,7 @@ class UNetDiscriminatorSN(nn.Module):
         that fed it, and conv8 / conv9 apply their producer's LeakyReLU derivative in the data-gradient epilogue."""
         from .. import hip_autograd_bf16 as B
         skip = self.skip_connection
+        sn = self._sn_weights()
         # x0, x1, x2 are stored pixel-unshuffled ONLY (u0, u1, u2: what the next strided conv reads): their producers write that
         # layout from the epilogue and the skip consumers read it where it is — no unshuffle passes, no second copy
         def conv(t, w, b, slope, nchw=False, **kw):   # noqa: F811 - adds the out_unshuffled option
@@ -111,16 +124,16 @@ class UNetDiscriminatorSN(nn.Module):
                                     kw.get('grad_premasked', False), kw.get('out_unshuffled', False), kw.get('skip_u2'))
         u0 = conv(B.ToCB16.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2, grad_premasked=True, out_unshuffled=True)
         s0, u0 = B.ForkU2Fn16.apply(u0, 0.2)
-        u1 = conv(u0, self.conv1.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
+        u1 = conv(u0, sn[1], None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
         s1, u1 = B.ForkU2Fn16.apply(u1, 0.2)
-        u2 = conv(u1, self.conv2.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
+        u2 = conv(u1, sn[2], None, 0.2, pre_unshuffled=True, grad_premasked=True, out_unshuffled=True)
         s2, u2 = B.ForkU2Fn16.apply(u2, 0.2)
         # conv3 / conv4 / conv5 feed only the resampling: its backward applies their LeakyReLU derivative (no stand-alone pass)
-        x3 = conv(u2, self.conv3.weight(), None, 0.2, pre_unshuffled=True, grad_premasked=True)
-        x4 = conv(B.Bilinear2xFn16.apply(x3, None, 0.2), self.conv4.weight(), None, 0.2, grad_premasked=True)
-        x5 = conv(B.Bilinear2xFn16.apply(x4, s2 if skip else None, 0.2, True), self.conv5.weight(), None, 0.2, grad_premasked=True)
+        x3 = conv(u2, sn[3], None, 0.2, pre_unshuffled=True, grad_premasked=True)
+        x4 = conv(B.Bilinear2xFn16.apply(x3, None, 0.2), sn[4], None, 0.2, grad_premasked=True)
+        x5 = conv(B.Bilinear2xFn16.apply(x4, s2 if skip else None, 0.2, True), sn[5], None, 0.2, grad_premasked=True)
         # conv6 adds the last skip in its epilogue (sign-keeping rounding: its LeakyReLU mask is recovered from the sum and x0)
-        x6 = conv(B.Bilinear2xFn16.apply(x5, s1 if skip else None, 0.2, True), self.conv6.weight(), None, 0.2, skip_u2=s0 if skip else None)
-        out = conv(x6, self.conv7.weight(), None, 0.2, grad_premasked=True)
-        out = conv(out, self.conv8.weight(), None, 0.2, input_slope=0.2, grad_premasked=True)
+        x6 = conv(B.Bilinear2xFn16.apply(x5, s1 if skip else None, 0.2, True), sn[6], None, 0.2, skip_u2=s0 if skip else None)
+        out = conv(x6, sn[7], None, 0.2, grad_premasked=True)
+        out = conv(out, sn[8], None, 0.2, input_slope=0.2, grad_premasked=True)
         return conv(out, self.conv9.weight, self.conv9.bias, 1.0, True, input_slope=0.2)  # fp32 NCHW logits

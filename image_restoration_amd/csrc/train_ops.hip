@@ -981,6 +981,123 @@ extern "C" int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v,
   return SR_OK;
 }
 
+// ---- the forward for all spectral-norm layers of a network at once: one launch per stage, blockIdx.z = layer ----
+namespace {
+struct SnOne {
+  const float* W;
+  float* u;
+  float* v;
+  float* w_sn;
+  float* sigma;
+  float* t;  // [parts][cols]
+  float* s;  // [rows]
+  int rows, cols, parts, chunk;
+};
+struct SnBatch {
+  SnOne l[SR_SN_BATCH_MAX];
+};
+// (the table is indexed by blockIdx.z: it lives in scratch for these launches, which are a few microseconds of latency-bound work)
+__global__ void sn_wt_u_batch_kernel(const SnBatch b) {
+  const SnOne& L = b.l[blockIdx.z];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= L.cols || (int)blockIdx.y >= L.parts) return;
+  const int r0 = blockIdx.y * L.chunk, r1 = min(r0 + L.chunk, L.rows);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += L.W[(long long)r * L.cols + c] * L.u[r];
+  L.t[(long long)blockIdx.y * L.cols + c] = s;
+}
+__global__ __launch_bounds__(256) void sn_w_v_batch_kernel(const SnBatch b) {
+  __shared__ float sh[4];
+  const SnOne& L = b.l[blockIdx.z];
+  const int r = blockIdx.x;
+  if (r >= L.rows) return;
+  float a = 0.f;
+  for (int c = threadIdx.x; c < L.cols; c += 256) a += L.W[(long long)r * L.cols + c] * L.v[c];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) L.s[r] = a;
+}
+// which 0: v = normalize(fold(t)); 1: u = normalize(s), sigma = u . s; 2 (eval): sigma = u . s
+__global__ __launch_bounds__(256) void sn_vec_batch_kernel(const SnBatch b, const int which, const float eps) {
+  __shared__ float sh[4];
+  const SnOne& L = b.l[blockIdx.z];
+  if (which == 2) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L.rows; i += 256) s += L.u[i] * L.s[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) L.sigma[0] = s;
+    return;
+  }
+  float* x = which == 0 ? L.t : L.s;
+  float* out = which == 0 ? L.v : L.u;
+  const int n = which == 0 ? L.cols : L.rows, parts = which == 0 ? L.parts : 1;
+  if (parts > 1) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      float s = 0.f;
+      for (int y = 0; y < parts; ++y) s += x[(long long)y * n + i];
+      x[i] = s;
+    }
+    __syncthreads();
+  }
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i] * x[i];
+  a = block_sum(a, sh);
+  const float nrm = fmaxf(sqrtf(a), eps);
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = x[i] / nrm;
+  if (which == 1 && threadIdx.x == 0) L.sigma[0] = a / nrm;
+}
+__global__ void sn_scale_batch_kernel(const SnBatch b) {
+  const SnOne& L = b.l[blockIdx.z];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long long)L.rows * L.cols) L.w_sn[i] = L.W[i] / L.sigma[0];
+}
+}  // namespace
+
+extern "C" int sr_spectral_norm_fwd_batch_f32(const sr_sn_layer* layers, int n_layers, int update, float eps, void* ws, size_t ws_bytes,
+                                              void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SR_CHECK_ARG(layers && n_layers > 0 && n_layers <= SR_SN_BATCH_MAX && ws, "sr_spectral_norm_fwd_batch_f32: 1..%d layers", SR_SN_BATCH_MAX);
+  SnBatch b = {};
+  size_t need = 0;
+  int max_cols = 0, max_rows = 0, max_parts = 0;
+  long long max_n = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const sr_sn_layer& a = layers[i];
+    SR_CHECK_ARG(a.w_orig && a.u && a.v && a.w_sn && a.sigma && a.rows > 0 && a.cols > 0, "sr_spectral_norm_fwd_batch_f32: bad layer %d", i);
+    SnOne& L = b.l[i];
+    L.W = a.w_orig;
+    L.u = a.u;
+    L.v = a.v;
+    L.w_sn = a.w_sn;
+    L.sigma = a.sigma;
+    L.rows = a.rows;
+    L.cols = a.cols;
+    L.parts = a.rows >= 512 ? 16 : a.rows >= 64 ? 8 : 1;  // as sr_spectral_norm_fwd_f32
+    L.chunk = (a.rows + L.parts - 1) / L.parts;
+    L.t = (float*)((char*)ws + need);
+    L.s = L.t + (size_t)16 * a.cols;
+    need += ((size_t)a.rows + (size_t)16 * a.cols) * sizeof(float);
+    need = (need + 255) / 256 * 256;
+    max_cols = a.cols > max_cols ? a.cols : max_cols;
+    max_rows = a.rows > max_rows ? a.rows : max_rows;
+    max_parts = L.parts > max_parts ? L.parts : max_parts;
+    max_n = (long long)a.rows * a.cols > max_n ? (long long)a.rows * a.cols : max_n;
+  }
+  SR_CHECK_ARG(ws_bytes >= need, "sr_spectral_norm_fwd_batch_f32: workspace %zu B < %zu B", ws_bytes, need);
+  for (int i = n_layers; i < SR_SN_BATCH_MAX; ++i) b.l[i] = b.l[0];
+  if (update) {
+    hipLaunchKernelGGL(sn_wt_u_batch_kernel, dim3(nblk(max_cols), max_parts, n_layers), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(sn_vec_batch_kernel, dim3(1, 1, n_layers), dim3(256), 0, stream, b, 0, eps);
+    hipLaunchKernelGGL(sn_w_v_batch_kernel, dim3(max_rows, 1, n_layers), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(sn_vec_batch_kernel, dim3(1, 1, n_layers), dim3(256), 0, stream, b, 1, eps);
+  } else {
+    hipLaunchKernelGGL(sn_w_v_batch_kernel, dim3(max_rows, 1, n_layers), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(sn_vec_batch_kernel, dim3(1, 1, n_layers), dim3(256), 0, stream, b, 2, eps);
+  }
+  hipLaunchKernelGGL(sn_scale_batch_kernel, dim3(nblk(max_n), 1, n_layers), dim3(256), 0, stream, b);
+  SR_CHECK_LAUNCH("spectral_norm_fwd_batch");
+  return SR_OK;
+}
+
 extern "C" int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float* u, const float* v,
                                         const float* sigma, int rows, int cols, float* g_worig, void* ws, size_t ws_bytes,
                                         void* stream_) {

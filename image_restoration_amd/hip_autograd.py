@@ -461,6 +461,64 @@ class SpectralNormFn(torch.autograd.Function):
         return gw, None, None, None, None
 
 
+class SpectralNormBatchFn(torch.autograd.Function):
+    """SpectralNormFn for all spectral-norm layers of a network in one call (sr_spectral_norm_fwd_batch_f32: one launch per stage
+    of the power iteration for all layers): forward(update, eps, w0, u0, v0, w1, u1, v1, ...) -> (w_sn0, w_sn1, ...); per layer the
+    same values as SpectralNormFn.  The backward stays per layer (one launch each)."""
+
+    @staticmethod
+    def forward(ctx, update, eps, *wuv):
+        lib = _lib.load()
+        nl = len(wuv) // 3
+        ws_, us, vs = [w.contiguous() for w in wuv[0::3]], wuv[1::3], wuv[2::3]
+        dev = ws_[0].device
+        outs = [torch.empty_like(w) for w in ws_]
+        sigmas = torch.empty(nl, dtype=torch.float32, device=dev)
+        table = (_lib.SnLayer * nl)()
+        need = 0
+        dims = []
+        for i, (w, u, v) in enumerate(zip(ws_, us, vs)):
+            rows = w.size(0)
+            cols = w.numel() // rows
+            dims.append((rows, cols))
+            table[i].w_orig, table[i].u, table[i].v = w.data_ptr(), u.data_ptr(), v.data_ptr()
+            table[i].rows, table[i].cols = rows, cols
+            table[i].w_sn, table[i].sigma = outs[i].data_ptr(), sigmas.data_ptr() + 4 * i
+            need += ((rows + 16 * cols) * 4 + 255) // 256 * 256
+        ws = scratch(dev, need + 256)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_spectral_norm_fwd_batch_f32(table, nl, int(update), eps, ws.data_ptr(), need + 256, _stream(dev)),
+                       'sr_spectral_norm_fwd_batch_f32')
+        if any(ctx.needs_input_grad[2::3]):   # u, v are updated in place by the next forward: the backward needs this forward's
+            ctx.save_for_backward(sigmas, *outs, *[u.clone() for u in us], *[v.clone() for v in vs])
+        ctx.dims = dims
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        nl = len(ctx.dims)
+        sigmas, outs, us, vs = saved[0], saved[1:1 + nl], saved[1 + nl:1 + 2 * nl], saved[1 + 2 * nl:1 + 3 * nl]
+        grads = [None, None]
+        for i, g in enumerate(gs):
+            if g is None:
+                grads += [None, None, None]
+                continue
+            rows, cols = ctx.dims[i]
+            dev = g.device
+            g = g.contiguous()
+            gw = torch.empty_like(g)
+            wsb = max((rows + cols) * 4, lib.sr_reduce_workspace_bytes(8) + 64)
+            ws = scratch(dev, wsb)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sr_spectral_norm_bwd_f32(g.data_ptr(), outs[i].data_ptr(), us[i].data_ptr(), vs[i].data_ptr(),
+                                                        sigmas.data_ptr() + 4 * i, rows, cols, gw.data_ptr(), ws.data_ptr(), wsb,
+                                                        _stream(dev)), 'sr_spectral_norm_bwd_f32')
+            grads += [gw, None, None]
+        return tuple(grads)
+
+
 class MaxPool2x2Fn(torch.autograd.Function):
     """nn.MaxPool2d(kernel_size=2, stride=2) on CB8 (sr_maxpool2x2_fwd_f32 / sr_maxpool2x2_bwd_f32)."""
 

@@ -227,6 +227,20 @@ int sr_spectral_norm_fwd_f32(const float* w_orig, float* u, float* v, int rows, 
                              float* w_sn, float* sigma, void* ws, size_t ws_bytes, void* stream);
 int sr_spectral_norm_bwd_f32(const float* g_wsn, const float* w_sn, const float* u, const float* v, const float* sigma,
                              int rows, int cols, float* g_worig, void* ws, size_t ws_bytes, void* stream);
+/* The same forward for up to SR_SN_BATCH_MAX weights at once (every spectral-norm layer of a UNetDiscriminatorSN forward): ONE launch
+ * per stage of the power iteration for all layers instead of five launches per layer; per layer the arithmetic, its order and the
+ * results (u, v, sigma, w_sn) are those of sr_spectral_norm_fwd_f32.  ws >= sum over layers of (rows + 16 cols) * 4 bytes. */
+#define SR_SN_BATCH_MAX 16
+typedef struct sr_sn_layer {
+  const float* w_orig;
+  float* u;
+  float* v;
+  int rows, cols;
+  float* w_sn;
+  float* sigma;
+} sr_sn_layer;
+int sr_spectral_norm_fwd_batch_f32(const sr_sn_layer* layers, int n_layers, int update, float eps, void* ws, size_t ws_bytes,
+                                   void* stream);
 
 /* out = a + b (skip connections of UNetDiscriminatorSN); n multiple of 4. */
 int sr_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -115,3 +115,28 @@ def test_esrgan_step_with_unet_discriminator_on_sr_tiles(cuda):
         log = model.get_current_log()
         assert all(np.isfinite(v) for v in log.values()), log
     assert float((model.optimizer_d.flat_p - d0).abs().max()) > 0
+
+
+def test_batched_spectral_norm_equals_the_per_layer_calls_bit_for_bit(cuda):
+    """sr_spectral_norm_fwd_batch_f32 (all spectral-norm layers of a forward, one launch per stage) against sr_spectral_norm_fwd_f32
+    per layer: normalised weights, sigma-dependent gradients and the in-place power-iteration buffers, train and eval mode."""
+    from image_restoration_amd import hip_autograd as A
+    torch.manual_seed(3)
+    shapes = [(128, 64, 4, 4), (256, 128, 4, 4), (512, 256, 4, 4), (256, 512, 3, 3), (128, 256, 3, 3), (64, 128, 3, 3), (64, 64, 3, 3), (24, 8, 3, 3)]
+    for update in (True, False):
+        ws = [torch.randn(*s_, device=cuda).requires_grad_(True) for s_ in shapes]
+        ws2 = [w.detach().clone().requires_grad_(True) for w in ws]
+        us = [torch.nn.functional.normalize(torch.randn(s_[0], device=cuda), dim=0) for s_ in shapes]
+        vs = [torch.nn.functional.normalize(torch.randn(s_[1] * s_[2] * s_[3], device=cuda), dim=0) for s_ in shapes]
+        us2, vs2 = [u.clone() for u in us], [v.clone() for v in vs]
+        flat = []
+        for w, u, v in zip(ws, us, vs):
+            flat += [w, u, v]
+        outs = A.SpectralNormBatchFn.apply(update, 1e-12, *flat)
+        ones = [A.SpectralNormFn.apply(w, u, v, update, 1e-12) for w, u, v in zip(ws2, us2, vs2)]
+        gs = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(list(outs), gs)
+        torch.autograd.backward(ones, gs)
+        for i in range(len(shapes)):
+            assert torch.equal(outs[i], ones[i]) and torch.equal(us[i], us2[i]) and torch.equal(vs[i], vs2[i]), (update, i)
+            assert torch.equal(ws[i].grad, ws2[i].grad), (update, i)
