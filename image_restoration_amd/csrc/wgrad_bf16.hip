@@ -356,6 +356,7 @@ struct RdbWgradParams {
   float* bslab;
   long long x_ns, dy_ns;
   int H, W, cin_blocks, strips, rows_per_wg, row_splits, nitems, splits;
+  int xcd_map;     // 1: the items of a pixel split sit on ONE XCD (below)
   long long* dbg;  // development: per-wave phase clocks
 };
 struct RdbItems {
@@ -381,8 +382,19 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
   constexpr int XRING = RDB_XRING, DUMP = RDB_DUMP, L = RDB_L;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split_i = blockIdx.x / p.nitems;
-  const int item_i = blockIdx.x - split_i * p.nitems;
+  // The items of one pixel split read the same rows of X at the same pace.  Workgroups are dealt round-robin over the 8 XCDs, each
+  // with its own L2: with the items as the fastest index the siblings land on different XCDs and every item fetches its rows from
+  // HBM for itself (measured: HBM traffic = the staged bytes).  Here workgroup b runs on XCD b & 7 and the items of a split are 8
+  // ids apart: same XCD, dispatched back to back, so the first sibling's fetch serves the others out of that L2.
+  int split_i, item_i;
+  if (p.xcd_map) {
+    const int k = blockIdx.x >> 3;
+    item_i = k % p.nitems;
+    split_i = (k / p.nitems) * 8 + (blockIdx.x & 7);
+  } else {
+    split_i = blockIdx.x / p.nitems;
+    item_i = blockIdx.x - split_i * p.nitems;
+  }
 #define RDB_SEL(f) \
   (item_i == 0 ? i0.f : item_i == 1 ? i1.f : item_i == 2 ? i2.f : item_i == 3 ? i3.f : item_i == 4 ? i4.f : item_i == 5 ? i5.f : item_i == 6 ? i6.f : i7.f)
   struct {
@@ -542,13 +554,10 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
       read_b(0, 0, fb[0]);
 #pragma unroll
       for (int seg = 0; seg < 4; ++seg) {
-        {
-          long long ti2 = 0;
-          if (p.dbg) ti2 = __builtin_readcyclecounter();
+        // (no clock reads in here: s_memtime is a scalar-memory operation, and with one possibly outstanding the compiler drains
+        // lgkmcnt to 0 around it — the read pipeline with it)
 #pragma unroll
-          for (int uu = seg; uu < L; uu += 4) issue_one(s + NSTG - 1, uu);
-          if (p.dbg) tk[4] += __builtin_readcyclecounter() - ti2;
-        }
+        for (int uu = seg; uu < L; uu += 4) issue_one(s + NSTG - 1, uu);
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
           const int cur = (seg * 3 + ty) & 1;
@@ -605,6 +614,7 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
 }
 
 long long* g_wgrad_phase_clocks = nullptr;
+int g_rdb_xcd_map = 1;  // development switch (sr_dev_set_wgrad_xcd_map)
 
 struct SlabCarve {
   float *slab, *bslab, *part, *bpart;
@@ -835,6 +845,7 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
   long long splits;
   rdb_grid(P, n, h, w, &p.rows_per_wg, &p.row_splits, &splits);
   p.splits = (int)splits;
+  p.xcd_map = g_rdb_xcd_map && splits % 8 == 0;
   long long soff = 0, boff = 0;
   for (int i = 0; i < P.nitems; ++i) {
     items.it[i] = P.items[i];
@@ -922,6 +933,8 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
 
 // Development aid (tools/bf16_phase.py; not part of the ABI): per-wave phase clocks of the next launches.
 extern "C" void sr_dev_wgrad_bf16_phase_clocks(void* buf) { g_wgrad_phase_clocks = (long long*)buf; }
+// Development switch (not part of the ABI): 0 = the dense block's weight-gradient items in plain order (items fastest).
+extern "C" void sr_dev_set_wgrad_xcd_map(int on) { g_rdb_xcd_map = on; }
 
 extern "C" size_t sr_conv3x3_wgrad_slab_bytes_bf16(int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return 0;

@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
            bytes / ms / 1e9, bytes / ms / 1e6 / cus, bytes / (ms * 1e-3) / cus / clk, clk / 1e9);
   };
   for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {
-    for (int span : {32, 4096}) {
+    for (int span : {32, 64, 128, 256, 1024, 4096}) {  // per workgroup: TCP-resident, L2-resident (<= 128 KB x 32 workgroups per XCD), Infinity Cache, HBM
       run("dma  depth1 (wait each)", fill_kernel<0, 1>, cus * wg_per_cu, span);
       run("dma  depth2", fill_kernel<0, 2>, cus * wg_per_cu, span);
       run("vgpr (load + ds_write)", fill_kernel<1, 1>, cus * wg_per_cu, span);

@@ -23,11 +23,14 @@ def run_rdb(n, h, w, nf=64, gc=32):
     lib.sr_dev_wgrad_bf16_phase_clocks(None)
     torch.cuda.synchronize()
     t = dbg.cpu().view(-1, 8)
+    slot = (torch.arange(t.shape[0]) % 8)[t[:, 0] > 1e9]
     t = t[t[:, 0] > 1e9].double()
     t0 = t[:, 0].min()
     for item in range(4):
         u = t[t[:, 7] == item]
         if len(u) == 0: continue
+        sl = slot[t[:, 7] == item]
+        print('   wait + barrier per wave slot (cycles, of total): ' + ' '.join(f'{float(u[sl == k][:, 2].mean()):.0f}' for k in range(8)), flush=True)
         print(f'rdb item {item}: waves={len(u)} start spread {float(u[:,0].max()-t0):.0f} | first wait {float(u[:,1].mean()):.0f} | later waits '
               f'{float(u[:,2].mean()):.0f} (min {float(u[:,2].min()):.0f} max {float(u[:,2].max()):.0f}) | issue {float(u[:,6].mean()):.0f} | loop end {float(u[:,3].mean()):.0f} | total {float(u[:,4].mean()):.0f} '
               f'| steps {float(u[:,5].mean()):.0f} | end max {float((u[:,0]+u[:,4]).max()-t0):.0f}', flush=True)

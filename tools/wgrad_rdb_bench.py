@@ -1,5 +1,5 @@
 """Times sr_rdb_wgrad_bf16 (all weight gradients of one dense block: wgrad_rdb_bf16_kernel + its two reduction launches).
-usage: python tools/wgrad_rdb_bench.py [n h w]"""
+usage: [XCD_MAP=0|1] python tools/wgrad_rdb_bench.py [n h w]"""
 import ctypes as C
 import os
 import sys
@@ -20,7 +20,11 @@ ptrs = (C.c_void_p * 10)(*[g.data_ptr() for g in grads])
 nbytes = lib.sr_rdb_wgrad_slab_bytes_bf16(n, h, w, nf, gc)
 slab = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
 flops = 2.0 * 9 * n * h * w * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64)
-for tri in (0, 1):
+lib.sr_dev_set_wgrad_xcd_map.argtypes = [C.c_int]
+lib.sr_dev_set_wgrad_xcd_map.restype = None
+modes = (int(os.environ['XCD_MAP']),) if 'XCD_MAP' in os.environ else (0, 1, 0, 1, 0, 1)
+for tri in modes:
+    lib.sr_dev_set_wgrad_xcd_map(tri)
     def run():
         _lib.check(lib.sr_rdb_wgrad_bf16(cat.data_ptr(), D.data_ptr(), cat[0].numel(), n, h, w, nf, gc, ptrs, 0.2, 0, slab.data_ptr(), nbytes,
                                          torch.cuda.current_stream().cuda_stream), 'sr_rdb_wgrad_bf16')
@@ -34,4 +38,4 @@ for tri in (0, 1):
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 50 * 1e3
-    print(f'run {tri}: {us:.1f} us per block (kernel + reductions), {flops / us / 1e6:.0f} TFLOP/s   n={n} {h}x{w}', flush=True)
+    print(f'xcd_map {tri}: {us:.1f} us per block (kernel + reductions), {flops / us / 1e6:.0f} TFLOP/s   n={n} {h}x{w}', flush=True)
