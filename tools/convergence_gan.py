@@ -1,5 +1,6 @@
-"""End-to-end check of the GAN recipe on the HIP path: ESRGANModel (L1 + perceptual + relativistic GAN, VGG discriminator) on
-smooth synthetic pairs, fp32 vs bf16 for every component.  usage: python tools/convergence_gan.py [fp32|bf16] [iters]"""
+"""End-to-end check of the GAN recipe on the HIP path: ESRGANModel (L1 + perceptual + relativistic GAN; VGG discriminator, or the
+spectrally normalised U-Net of the C3 step) on smooth synthetic pairs, fp32 vs bf16 for every component.
+usage: python tools/convergence_gan.py [fp32|bf16] [iters] [vgg|unet]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,12 +9,13 @@ from image_restoration_amd.models import build_model
 from image_restoration_amd.utils.synth import smooth_pairs
 
 
-def run(dtype, iters):
+def run(dtype, iters, disc='vgg'):
     torch.manual_seed(0)
     adam = dict(type='Adam', lr=5e-4, weight_decay=0, betas=[0.9, 0.99])
     opt = dict(name='gan', model_type='ESRGANModel', scale=4, num_gpu=1, dist=False, rank=0, world_size=1, is_train=True,
                network_g=dict(type='RRDBNet', num_in_ch=3, num_out_ch=3, scale=4, num_feat=32, num_block=2, num_grow_ch=16, compute_dtype=dtype),
-               network_d=dict(type='VGGStyleDiscriminator128', num_in_ch=3, num_feat=16, compute_dtype=dtype),
+               network_d=(dict(type='VGGStyleDiscriminator128', num_in_ch=3, num_feat=16, compute_dtype=dtype) if disc == 'vgg' else
+                          dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=16, skip_connection=True, compute_dtype=dtype)),
                path=dict(pretrain_network_g=None, strict_load_g=True, pretrain_network_d=None),
                train=dict(ema_decay=0, optim_g=dict(adam), optim_d=dict(adam),
                           scheduler=dict(type='MultiStepLR', milestones=[10 ** 6], gamma=0.5), total_iter=iters, warmup_iter=-1,
@@ -40,5 +42,6 @@ def run(dtype, iters):
 
 if __name__ == '__main__':
     dtype = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
-    for it, p, log in run(dtype, int(sys.argv[2]) if len(sys.argv) > 2 else 250):
-        print(f'{dtype} iter {it:4d} val PSNR {p:6.2f} dB  {log}')
+    disc = sys.argv[3] if len(sys.argv) > 3 else 'vgg'
+    for it, p, log in run(dtype, int(sys.argv[2]) if len(sys.argv) > 2 else 250, disc):
+        print(f'{dtype} {disc} iter {it:4d} val PSNR {p:6.2f} dB  {log}')
