@@ -374,6 +374,9 @@ static_assert(RDB_LDS <= 160 * 1024 && RDB_L * (RDB_NSTG - 2) < 64, "rdb wgrad g
 
 // The item table travels as eight separate by-value arguments: an array inside the parameter struct makes hipcc copy
 // the whole struct to scratch and re-load fields inside the loop behind vmcnt(0) waits (which drain the row prefetch).
+// NSEG: 16-pixel k-steps of a row that hold pixels (4 = a 64-pixel strip; 2 for images at most 32 pixels wide — the reference recipe's
+// 32x32 patches, train_ESRGAN_x4.yml:24 — where the other two would multiply zeros: half of the launch's MFMAs and operand reads).
+template <int NSEG>
 __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParams p, const RdbItem i0, const RdbItem i1,
                                                              const RdbItem i2, const RdbItem i3, const RdbItem i4,
                                                              const RdbItem i5, const RdbItem i6, const RdbItem i7) {
@@ -553,11 +556,11 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
       read_a(0, fa[0]);
       read_b(0, 0, fb[0]);
 #pragma unroll
-      for (int seg = 0; seg < 4; ++seg) {
+      for (int seg = 0; seg < NSEG; ++seg) {
         // (no clock reads in here: s_memtime is a scalar-memory operation, and with one possibly outstanding the compiler drains
         // lgkmcnt to 0 around it — the read pipeline with it)
 #pragma unroll
-        for (int uu = seg; uu < L; uu += 4) issue_one(s + NSTG - 1, uu);
+        for (int uu = seg; uu < L; uu += NSEG) issue_one(s + NSTG - 1, uu);
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
           const int cur = (seg * 3 + ty) & 1;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(512) void wgrad_rdb_bf16_kernel(const RdbWgradParam
           if (ty < 2) {
             read_b(seg, ty + 1, fb[cur ^ 1]);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-          } else if (seg < 3) {
+          } else if (seg < NSEG - 1) {
             read_a(seg + 1, fa[(seg + 1) & 1]);
             read_b(seg + 1, 0, fb[cur ^ 1]);
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -863,7 +866,8 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
     set_error("rdb_wgrad_bf16: slab too small (need %zu B of tiles)", (size_t)soff * sizeof(float));
     return SR_ENOSPACE;
   }
-  if (int rc = sr::ensure_dynamic_lds((const void*)wgrad_rdb_bf16_kernel, RDB_LDS)) return rc;  // once per (kernel, device)
+  const auto kern = w <= 32 ? wgrad_rdb_bf16_kernel<2> : wgrad_rdb_bf16_kernel<4>;
+  if (int rc = sr::ensure_dynamic_lds((const void*)kern, RDB_LDS)) return rc;  // once per (kernel, device)
   const bool prof = prof_on();
   if (prof) {
     sr_launch_record r = {};
@@ -883,7 +887,7 @@ int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, i
     r.bytes = by;
     prof_begin(stream, r);
   }
-  hipLaunchKernelGGL(wgrad_rdb_bf16_kernel, dim3((unsigned)(splits * P.nitems)), dim3(512), RDB_LDS, stream, p, items.it[0],
+  hipLaunchKernelGGL(kern, dim3((unsigned)(splits * P.nitems)), dim3(512), RDB_LDS, stream, p, items.it[0],
                      items.it[1], items.it[2], items.it[3], items.it[4], items.it[5], items.it[6], items.it[7]);
   if (prof) prof_end(stream);
   SR_CHECK_LAUNCH("wgrad_rdb_bf16 launch");

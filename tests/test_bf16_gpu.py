@@ -285,7 +285,9 @@ def test_esrgan_model_bf16_first_iteration_tracks_reference(golden):
 
 
 @pytest.mark.parametrize('nf,gc,n,h,w', [(64, 32, 2, 24, 72), (64, 32, 8, 32, 64), (16, 8, 3, 17, 40), (48, 24, 2, 16, 16), (64, 32, 3, 40, 100),
-                                         (64, 32, 1, 5, 7), (64, 32, 1, 1, 70), (64, 32, 32, 128, 128)])
+                                         (64, 32, 1, 5, 7), (64, 32, 1, 1, 70), (64, 32, 32, 128, 128),
+                                         # at most 32 pixels wide: the two-k-step instance (the recipe's 32x32 patches, ragged, one column short)
+                                         (64, 32, 32, 32, 32), (64, 32, 3, 20, 17), (64, 32, 2, 33, 31)])
 def test_rdb_wgrad_bf16_single_launch_matches_per_conv_launches(nf, gc, n, h, w):
     """sr_rdb_wgrad_bf16 (all five convs of a dense block, one launch) == five sr_conv3x3_wgrad_bf16 calls on the same
     buffers up to fp32 summation order (2e-5 of the largest gradient entry), including accumulate and the conv5 scale."""
