@@ -42,6 +42,7 @@ struct WgradParamsH {
   int cin_tile0, cout_tile0;
   int gi;            // cin groups per cout-group row: blockIdx.y = (row, column) of a grid of same-shaped tile groups
   int strips, rows_per_wg, row_splits;
+  int n, imgs_per_wg;  // a workgroup walks imgs_per_wg images (small images: the 36 KB tiles it leaves are its fixed cost)
   int src_shift;     // 1: x is read through the nearest x2 upsample
   long long* dbg;    // development: per-wave phase clocks (sr_dev_wgrad_bf16_phase_clocks)
 };
@@ -80,10 +81,12 @@ __device__ __forceinline__ void wait_vmcnt_w() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
-template <int CT, int IT, int KS, int R, int NSTG>
+// NSEG: 16-pixel k-steps of a strip row that can hold pixels (4 = the 64-pixel strip; 2 / 1 for images at most 32 / 16 pixels wide —
+// the deep layers of the VGG discriminator at 32x32 ... 4x4 — where the others would multiply zeros).
+template <int CT, int IT, int KS, int R, int NSTG, int NSEG = 4>
 struct WgradGeom {
   static constexpr int P = CT * IT, NW = P * KS;
-  static constexpr int UPW = R * 4 / KS;  // 16-pixel k-steps per wave per step
+  static constexpr int UPW = R * NSEG / KS;  // 16-pixel k-steps per wave per step
   static constexpr int XUNITS = (IT * 2 * PLP + 63) / 64, YUNITS = (CT * 2 * PLP + 63) / 64;
   static constexpr int XROWB = XUNITS * 1024, YROWB = YUNITS * 1024;
   static constexpr int NXR = NSTG * R + 2, NYR = NSTG * R;
@@ -93,14 +96,14 @@ struct WgradGeom {
   static constexpr int L = (UNITS_PER_STAGE + NW - 1) / NW;  // loads per wave per stage
   static constexpr int RED = P * (KS - 1) * 4096;
   static constexpr int LDS = (DUMP + 1024) > RED ? (DUMP + 1024) : RED;
-  static_assert(NW <= 8 && R * 4 % KS == 0 && UPW >= 1, "bad wave split");
+  static_assert(NW <= 8 && R * NSEG % KS == 0 && UPW >= 1, "bad wave split");
   static_assert(L * (NSTG - 2) < 64, "vmcnt is a 6-bit counter");
 };
 
-template <int CT, int IT, int KS, int R, int NSTG>
+template <int CT, int IT, int KS, int R, int NSTG, int NSEG = 4>
 __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const WgradParamsH p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using G = WgradGeom<CT, IT, KS, R, NSTG>;
+  using G = WgradGeom<CT, IT, KS, R, NSTG, NSEG>;
   constexpr int P = G::P, NW = G::NW, UPW = G::UPW, XUNITS = G::XUNITS, YUNITS = G::YUNITS, XROWB = G::XROWB, YROWB = G::YROWB;
   constexpr int NXR = G::NXR, NYR = G::NYR, XRING = G::XRING, DUMP = G::DUMP, L = G::L;
 
@@ -114,14 +117,14 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
   const int rs = t % p.row_splits;
   t /= p.row_splits;
   const int strip = t % p.strips;
-  const int n = t / p.strips;
+  const int n_first = (t / p.strips) * p.imgs_per_wg, n_last = min(n_first + p.imgs_per_wg, p.n);
   const int x0 = strip * 64;
   const int y_begin = rs * p.rows_per_wg;
   const int y_end = min(y_begin + p.rows_per_wg, p.H);
   const int nsteps = (y_end - y_begin + R - 1) / R;
 
-  const __bf16* xn = p.x + (long long)n * p.x_ns;
-  const __bf16* dyn = p.dy + (long long)n * p.dy_ns;
+  const __bf16* xn = p.x + (long long)n_first * p.x_ns;  // (the image under the loop below)
+  const __bf16* dyn = p.dy + (long long)n_first * p.dy_ns;
   const long long xplane = (long long)p.x_h * p.x_w * 16, yplane = (long long)p.H * p.W * 16;
   char* xring = smem;
   char* yring = smem + XRING;
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
   // stage s = X tap-rows [y_begin + 2 + sR, +R) and dY rows [y_begin + sR, +R); exactly L loads per wave.  Which unit of which
   // row a wave's uu-th load moves never changes, so its per-lane byte offset (channel block, column, half; beyond the buffer for
   // lanes outside the image) is computed once; a step only adds the row as the scalar offset of the buffer load.
-  const __amdgpu_buffer_rsrc_t x_rs =
+  __amdgpu_buffer_rsrc_t x_rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)((long long)p.cin_blocks * xplane * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t y_rs =
+  __amdgpu_buffer_rsrc_t y_rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)dyn, 0, (unsigned)((long long)p.cout_blocks * yplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0, 0x00020000);
   unsigned lane_off[L];
@@ -209,6 +212,15 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
 
   long long tk[5] = {0, 0, 0, 0, 0};
   if (p.dbg) tk[0] = __builtin_readcyclecounter();
+  for (int n = n_first; n < n_last; ++n) {
+  if (n > n_first) {  // the next image of this workgroup: the rings are free (every load drained, every read behind the barrier)
+    wait_vmcnt_w<0>();
+    __syncthreads();
+    xn = p.x + (long long)n * p.x_ns;
+    dyn = p.dy + (long long)n * p.dy_ns;
+    x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)((long long)p.cin_blocks * xplane * 2), 0x00020000);
+    y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dyn, 0, (unsigned)((long long)p.cout_blocks * yplane * 2), 0x00020000);
+  }
   // prologue: the two halo tap-rows, then NSTG-1 stages in flight
   for (int u = wave; u < 2 * XUNITS; u += NW) load_x(y_begin + u / XUNITS, u % XUNITS);
 #pragma unroll
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
 #pragma unroll
     for (int uw = 0; uw < UPW; ++uw) {
       const int unit = ks * UPW + uw;
-      const int row = y + unit / 4, seg = unit % 4;
+      const int row = y + unit / NSEG, seg = unit % NSEG;
       {
         // all 20 operand fragments of this 16-pixel k-step (A: dY; B: X at the 9 tap shifts), one wait, 9 MFMAs
         s16x4 f[20];
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
       }
     }
   }
+  }  // images of this workgroup
   wait_vmcnt_w<0>();  // the tail's dummy loads target the dump KB; the rings are reused below
   __syncthreads();
   if (p.dbg) tk[3] = __builtin_readcyclecounter() - tk[0];
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(CT * IT * KS * 64) void wgrad_bf16_kernel(const Wgr
       }
       __syncthreads();
       if (ks == 0) {
-#pragma unroll
+#pragma unroll 1  // (rolled: unrolled sevenfold for KS = 8 the loads of all partial tiles were live at once and the kernel spilled)
         for (int k = 0; k < KS - 1; ++k) {
           const float* src = red + ((pair_w * (KS - 1) + k) * 1024) + lane * 4;
           if (tap < 9) {
@@ -640,10 +653,10 @@ SlabCarve carve_slab(void* base, size_t bytes) {
   return c;
 }
 
-template <int CT, int IT, int KS, int R, int NSTG>
-int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, int grows, int gi,
-                 const SlabCarve& sc, bool want_bias, hipStream_t stream) {
-  using G = WgradGeom<CT, IT, KS, R, NSTG>;
+template <int CT, int IT, int KS, int R, int NSTG, int NSEG>
+int launch_group_n(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, int grows, int gi,
+                   const SlabCarve& sc, bool want_bias, hipStream_t stream) {
+  using G = WgradGeom<CT, IT, KS, R, NSTG, NSEG>;
   constexpr int P = G::P;
   constexpr int lds = G::LDS;
   static_assert(lds <= 160 * 1024, "rings do not fit the LDS");
@@ -651,8 +664,14 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
   p.gi = gi;
-  // about one workgroup per CU over the whole launch: every workgroup leaves P fp32 tiles of 36 KB
-  const long long strips_total = (long long)d->n * p.strips;
+  // about one workgroup per CU over the whole launch: every workgroup leaves P fp32 tiles of 36 KB, whatever it multiplied — a
+  // workgroup of the VGG discriminator's 512-channel layers used to own ONE 8x8 or 4x4 image (1024 workgroups, a 300 MB slab for
+  // a 9 MB gradient); small images are walked several per workgroup
+  p.n = d->n;
+  long long ipw = (long long)d->n * p.strips * groups / 256;
+  ipw = ipw < 1 ? 1 : ipw > d->n ? d->n : ipw;
+  p.imgs_per_wg = (int)ipw;
+  const long long strips_total = (long long)sr::cdiv(d->n, (int)ipw) * p.strips;
   const int want = (int)(256 / (strips_total * groups)) > 1 ? (int)(256 / (strips_total * groups)) : 1;
   int rows = sr::cdiv(p.H, want);
   rows = (rows + R - 1) / R * R;
@@ -667,7 +686,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
   p.slab = sc.slab;
   p.bslab = want_bias ? sc.bslab : nullptr;
   p.dbg = g_wgrad_phase_clocks;
-  auto kern = wgrad_bf16_kernel<CT, IT, KS, R, NSTG>;
+  auto kern = wgrad_bf16_kernel<CT, IT, KS, R, NSTG, NSEG>;
   if (int rc = sr::ensure_dynamic_lds((const void*)kern, lds)) return rc;  // once per (kernel, device)
   const bool prof = sr::prof_on();
   if (prof) {
@@ -714,6 +733,19 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0,
   rr.dw = d->dweight;
   rr.db = want_bias ? d->dbias : nullptr;
   return sr::wgrad_reduce(rr, stream);
+}
+
+// the instance with as many k-steps per strip row as the image is wide (where the wave split of the shape allows it)
+template <int CT, int IT, int KS, int R, int NSTG>
+int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, int grows, int gi,
+                 const SlabCarve& sc, bool want_bias, hipStream_t stream) {
+  if constexpr (R % KS == 0) {
+    if (p.W <= 16) return launch_group_n<CT, IT, KS, R, NSTG, 1>(d, p, cout_tile0, cin_tile0, grows, gi, sc, want_bias, stream);
+  }
+  if constexpr (R * 2 % KS == 0) {
+    if (p.W <= 32) return launch_group_n<CT, IT, KS, R, NSTG, 2>(d, p, cout_tile0, cin_tile0, grows, gi, sc, want_bias, stream);
+  }
+  return launch_group_n<CT, IT, KS, R, NSTG, 4>(d, p, cout_tile0, cin_tile0, grows, gi, sc, want_bias, stream);
 }
 
 }  // namespace

@@ -76,6 +76,7 @@ class BaseModel:
         self.packs = OrderedDict()   # label ('g', 'd') -> NetPack
         self.schedulers = []
         self.log_dict = OrderedDict()
+        self._log_staged = None   # (names, device vector) of the last step, not yet read back (stage_loss_dict)
 
     # ------------------------------------------------------------------ interface of the pipelines
     def feed_data(self, data):
@@ -88,6 +89,15 @@ class BaseModel:
         raise NotImplementedError
 
     def get_current_log(self):
+        """The last step's losses as python floats (base_model.py:328-353 fills them every step with ``.item()``: one host
+        synchronisation per step, which here would drain the launch queue between steps — the read-back happens when somebody asks)."""
+        if self._log_staged is not None:
+            names, vec = self._log_staged
+            self._log_staged = None
+            self.log_dict = OrderedDict(zip(names, vec.tolist()))   # the synchronisation: the step's launches have finished
+            if self.device.type == 'cuda':
+                from .. import watchdog
+                watchdog.verify('get_current_log', synchronize=False)   # numbers of a step that timed out must not reach the log
         return self.log_dict
 
     # ------------------------------------------------------------------ networks
@@ -231,3 +241,17 @@ class BaseModel:
                 if self.opt['rank'] == 0:
                     vec /= self.opt['world_size']
             return OrderedDict(zip(names, vec.tolist()))
+
+    def stage_loss_dict(self, loss_dict):
+        """reduce_loss_dict without the read-back: the (rank-reduced) loss vector stays on the device until get_current_log()."""
+        names = list(loss_dict)
+        if not names:
+            self._log_staged, self.log_dict = None, OrderedDict()
+            return
+        with torch.no_grad():
+            vec = torch.stack([loss_dict[n].detach().float().mean() for n in names])
+            if self.distributed:
+                torch.distributed.reduce(vec, dst=0)
+                if self.opt['rank'] == 0:
+                    vec /= self.opt['world_size']
+        self._log_staged = (names, vec)

@@ -102,9 +102,11 @@ class SRModel(BaseModel):
                 book.charge(pre + 'style', style)
 
     def finish_step(self, book):
-        self.log_dict = self.reduce_loss_dict(book.entries)   # .tolist(): the step's launches have finished
+        self.stage_loss_dict(book.entries)   # read back by get_current_log(): no host synchronisation inside a step
         if self.device.type == 'cuda':
-            watchdog.verify('optimize_parameters', synchronize=False)   # invalid gradients must not pass as a step
+            # (without a synchronisation: reports what the abort words copied behind EARLIER launches say — a time-out surfaces one
+            # step later at the latest, and at every hand-over: get_current_log, save, test)
+            watchdog.verify('optimize_parameters', synchronize=False)
         if self.ema_decay > 0:
             self.gen.blend_shadow(self.ema_decay)
 

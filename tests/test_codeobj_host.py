@@ -1,6 +1,7 @@
 """What the compiler made of the kernels whose design depends on it (runs without a GPU: reads libsr_hip.so's gfx950 code objects).
 
-* ``rdb_fused_bf16_kernel<0..2>`` and ``conv_stream_bf16_kernel<...>`` are one workgroup of 8 waves per CU with 150-159 KB of LDS and
+* ``rdb_fused_bf16_kernel<0..2>``, ``conv_stream_bf16_kernel<...>`` and the bf16 weight-gradient kernels (``wgrad_bf16_kernel<...>``,
+  ``wgrad_rdb_bf16_kernel<2|4>``) are one workgroup of 8 waves per CU with 150-159 KB of LDS and
   counted ``s_waitcnt vmcnt`` schedules computed from the issue order of a wave: a register spill adds ``scratch_load`` / ``scratch_store``
   to that order (they share ``vmcnt`` with the LDS-DMA) and the design collapses silently — slower, and in the fused kernel the
   counted waits would cover the wrong operations.  So: no scratch, at most 256 VGPRs, no spills.
@@ -55,7 +56,8 @@ def _kernels(code_objects, needle):
     return {n: (path, md) for path, ks in code_objects for n, md in ks.items() if needle in n}
 
 
-@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4)])
+@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4), ('wgrad_bf16_kernel', 10),
+                                             ('wgrad_rdb_bf16_kernel', 2)])
 def test_one_workgroup_per_cu_kernels_have_no_scratch_and_no_spills(code_objects, needle, at_least):
     ks = _kernels(code_objects, needle)
     assert len(ks) >= at_least, sorted(ks)
