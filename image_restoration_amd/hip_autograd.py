@@ -63,13 +63,14 @@ class ConvFn(torch.autograd.Function):
         k = weight.size(2)
         src = _cb8(x)
         if k == 3:
-            out = H.conv3x3(src, H.PackedConv(weight, bias), act_slope=act_slope)
+            out = H.conv3x3(src, H.cached_pack('f32 fwd', weight, bias, lambda: H.PackedConv(weight, bias)), act_slope=act_slope)
         elif k == 4:
-            out = H.conv4x4s2(src, H.PackedConv4x4s2(weight, bias), act_slope=act_slope)
+            out = H.conv4x4s2(src, H.cached_pack('f32 fwd', weight, bias, lambda: H.PackedConv4x4s2(weight, bias)), act_slope=act_slope)
         else:
             raise NotImplementedError(f'kernel size {k}')
         ctx.save_for_backward(x, weight, out.buf if act_slope != 1.0 else None)
         ctx.act_slope, ctx.has_bias, ctx.k = act_slope, bias is not None, k
+        ctx.param = weight if isinstance(weight, torch.nn.Parameter) else None   # key of the transposed image's cache entry
         return out.buf
 
     @staticmethod
@@ -93,9 +94,10 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if need_x:
             if k == 3:
-                dx = H.conv3x3(dzc, H.PackedConv(weight, None, mode=1)).buf
+                dx = H.conv3x3(dzc, H.cached_pack('f32 dgrad', ctx.param, None, lambda: H.PackedConv(weight, None, mode=1))).buf
             else:
-                dx = H.conv4x4s2_dgrad(dzc, H.PackedConv4x4s2(weight, None, mode=1), src.h, src.w).buf
+                dx = H.conv4x4s2_dgrad(dzc, H.cached_pack('f32 dgrad', ctx.param, None, lambda: H.PackedConv4x4s2(weight, None, mode=1)),
+                                       src.h, src.w).buf
             if dx.size(1) != x.size(1):  # dgrad writes roundup8(cin) channels == x's blocks
                 dx = dx[:, :x.size(1)].contiguous()
         if need_w or (need_b and ctx.has_bias):

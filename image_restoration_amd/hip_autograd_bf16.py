@@ -98,16 +98,20 @@ class ConvFn16(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act_slope, out_nchw, pre_unshuffled=False, input_slope=1.0, grad_premasked=False,
                 out_unshuffled=False, skip_u2=None):
         k = weight.size(2)
+        param = weight   # (the cache below keys on the parameter object)
         weight = weight.detach().contiguous().float()
         cout, cin = weight.shape[:2]
         if k == 4:
             src = _cb16(x.contiguous() if pre_unshuffled else _unshuffle2(x.contiguous()))
-            w3 = _w4_as_w3(weight)
         elif k == 3:
-            src, w3 = _cb16(x.contiguous()), weight
+            src = _cb16(x.contiguous())
         else:
             raise NotImplementedError(f'kernel size {k}')
-        pc = H.PackedConvBF16(w3, bias)
+
+        def build():
+            w3_ = _w4_as_w3(weight) if k == 4 else weight
+            return w3_, H.PackedConvBF16(w3_, bias)
+        w3, pc = H.cached_pack('bf16 fwd', param, bias, build)
         s2 = cin if (k == 4 and cin % 64 == 0) else 0  # lets the kernel skip the zero taps of the 3x3 embedding
         if out_nchw:
             assert act_slope == 1.0
@@ -132,6 +136,7 @@ class ConvFn16(torch.autograd.Function):
         ctx.cout, ctx.cin, ctx.x_cb = cout, cin, x.size(1)
         ctx.pre_unshuffled, ctx.input_slope, ctx.grad_premasked, ctx.s2 = pre_unshuffled, input_slope, grad_premasked, s2
         ctx.out_unshuffled = out_unshuffled
+        ctx.param = param if isinstance(param, torch.nn.Parameter) else None   # key of the transposed image's cache entry
         assert input_slope == 1.0 or k == 3, 'the input mask applies to 3x3 convs'
         return ret
 
@@ -166,10 +171,11 @@ class ConvFn16(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dw = db = None
         if need_x:
+            pct = H.cached_pack('bf16 dgrad', ctx.param, None, lambda: H.PackedConvBF16(w3, None, mode=1))
             if ctx.input_slope != 1.0:  # dL/d(pre-activation of the producer): mask = this conv's own input
-                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1), mask=src, mask_slope=ctx.input_slope).buf
+                d = H.conv3x3_bf16(dzc, pct, mask=src, mask_slope=ctx.input_slope).buf
             else:
-                d = H.conv3x3_bf16(dzc, H.PackedConvBF16(w3, None, mode=1), s2_channels=ctx.s2, s2_side=1).buf  # cin3 channels
+                d = H.conv3x3_bf16(dzc, pct, s2_channels=ctx.s2, s2_side=1).buf  # cin3 channels
             dx = _unshuffle2(d, inverse=True) if ctx.k == 4 and not ctx.pre_unshuffled else d
             if dx.size(1) != ctx.x_cb:
                 dx = dx[:, :ctx.x_cb].contiguous()

@@ -5,6 +5,7 @@ libsr_hip.so call.  Activations between ops are in the CB8 layout
 ``[N][C/8][H][W][8]`` (class ``CB8``); channel slices are views (pointer + parent stride).
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -16,6 +17,35 @@ def _stream(dev):
 
 
 _scratch = {}
+
+# ---- weight images of long-lived parameters are packed once per change, not once per call ----
+# The discriminators and the perceptual extractor run their convs one autograd function at a time; every call packed its weight
+# (and, in the backward, the transposed image) again: the ESRGAN step runs the discriminator five times on the same weights.
+# A cached image is valid while the parameter object, its storage address, its torch version counter and its write epoch are the
+# same.  The epoch covers writers torch cannot see: the fused Adam / EMA kernels write through raw pointers (optim.FlatAdam tags
+# its parameters with its epoch cell and bumps it per step); invalidate_packs() is the global form.  Only nn.Parameter weights
+# are cached: temporaries (a spectrally normalised weight is a new tensor every forward) would pin memory and can alias addresses.
+# (An in-place write through ``param.data`` is invisible to all of these: call invalidate_packs() after one.)
+_pack_epoch = [0]
+_pack_cache = {}
+
+
+def invalidate_packs():
+    _pack_epoch[0] += 1
+
+
+def cached_pack(kind, weight, bias, build):
+    if not isinstance(weight, torch.nn.Parameter):
+        return build()
+    sig = (weight.data_ptr(), weight._version, getattr(weight, '_sr_epoch', _pack_epoch)[0], _pack_epoch[0],
+           None if bias is None else (bias.data_ptr(), bias._version))
+    key = (id(weight), kind)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == sig:
+        return hit[2]
+    val = build()
+    _pack_cache[key] = (weakref.ref(weight), sig, val)
+    return val
 
 
 def scratch(dev, nbytes, tag='ws'):

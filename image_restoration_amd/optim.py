@@ -46,6 +46,7 @@ class FlatAdam:
             self.offsets.append(off)
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = off
+        self._epoch = [0]
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -56,6 +57,7 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                p._sr_epoch = self._epoch   # hip_ops.cached_pack: this optimiser rewrites the parameter behind torch's version counter
         self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False)]
         self.step_count = 0
@@ -99,6 +101,7 @@ class FlatAdam:
         self._invalidate()
 
     def _invalidate(self):
+        self._epoch[0] += 1
         for m in self.modules:
             if hasattr(m, 'invalidate_packed'):
                 m.invalidate_packed()
