@@ -19,6 +19,9 @@ if len(sys.argv) > 5:
     opt['network_g']['compute_dtype'] = sys.argv[5]
 if len(sys.argv) > 6:
     opt['network_d']['compute_dtype'] = sys.argv[6]
+if os.environ.get('CHAIN_F32'):   # development: the fp32 dense block as one persistent launch (off by default)
+    from image_restoration_amd import _lib
+    _lib.check(_lib.load().sr_set_conv_chain_f32(int(os.environ['CHAIN_F32'])), 'sr_set_conv_chain_f32')
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ))).cuda()
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ))).cuda()
