@@ -653,6 +653,16 @@ SlabCarve carve_slab(void* base, size_t bytes) {
   return c;
 }
 
+// Images a workgroup should walk at least: it leaves P tiles of 36 KB (~28 thousand cycles of its HBM share) whatever it multiplied,
+// and an image costs it H rows x 9 MFMAs per live 16-pixel k-step plus ~2 thousand cycles of ring prologue.
+int min_imgs_per_wg(int n, int H, int W) {
+  const int nseg = W <= 16 ? 1 : W <= 32 ? 2 : 4;
+  const long long per_image = (long long)H * nseg * 288 + 2000;
+  const long long m = (28000 + per_image - 1) / per_image;
+  if (m < 3) return 1;  // (32x32 and larger: measured faster with one image, or a row range of one, per workgroup)
+  return (int)(m > n ? n : m);
+}
+
 template <int CT, int IT, int KS, int R, int NSTG, int NSEG>
 int launch_group_n(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile0, int cin_tile0, int grows, int gi,
                    const SlabCarve& sc, bool want_bias, hipStream_t stream) {
@@ -669,10 +679,12 @@ int launch_group_n(const sr_conv3x3_wgrad_desc* d, WgradParamsH p, int cout_tile
   // a 9 MB gradient); small images are walked several per workgroup
   p.n = d->n;
   long long ipw = (long long)d->n * p.strips * groups / 256;
-  ipw = ipw < 1 ? 1 : ipw > d->n ? d->n : ipw;
+  const int ipw_min = min_imgs_per_wg(d->n, p.H, p.W);
+  ipw = ipw < ipw_min ? ipw_min : ipw > d->n ? d->n : ipw;
   p.imgs_per_wg = (int)ipw;
   const long long strips_total = (long long)sr::cdiv(d->n, (int)ipw) * p.strips;
-  const int want = (int)(256 / (strips_total * groups)) > 1 ? (int)(256 / (strips_total * groups)) : 1;
+  // (rows of an image are split over workgroups only where one image is more than a workgroup's worth: never below ipw_min's bound)
+  const int want = ipw_min > 1 ? 1 : (int)(256 / (strips_total * groups)) > 1 ? (int)(256 / (strips_total * groups)) : 1;
   int rows = sr::cdiv(p.H, want);
   rows = (rows + R - 1) / R * R;
   p.rows_per_wg = rows;
@@ -1029,7 +1041,9 @@ extern "C" int sr_conv3x3_wgrad_bf16(const sr_conv3x3_wgrad_desc* d, void* strea
     if (cn == 2 && its >= 4 && its / 4 <= 32) {
       const int gi = its / 4, rows_left = (cts - c0) / 2;
       // slab: groups * workgroups tiles of 8 pairs; partial buffers: groups * 8 pairs <= 256 and rows * 2 * 32 bias floats
-      long long cap = (long long)(sc.wslab_bytes / ((size_t)8 * 9 * 1024 * sizeof(float))) / (strips_total > 0 ? strips_total : 1);
+      // (workgroups per tile group: at least min_imgs_per_wg images each — launch_group_n may give a workgroup more, never fewer)
+      const long long wgs_per_group = (long long)sr::cdiv(d->n, min_imgs_per_wg(d->n, p.H, p.W)) * p.strips;
+      long long cap = (long long)(sc.wslab_bytes / ((size_t)8 * 9 * 1024 * sizeof(float))) / (wgs_per_group > 0 ? wgs_per_group : 1);
       if (cap > 32) cap = 32;
       SR_CHECK_ARG(cap >= 1, "sr_conv3x3_wgrad_bf16: slab too small for one tile group of %lld strips", strips_total);
       long long rows = 1;

@@ -1,5 +1,6 @@
 """Development aid: the conv / weight-gradient launches of one C3 training step (bf16 RRDBNet + bf16 UNetDiscriminatorSN, batch 32 of 128x128),
-grouped by (kernel, cin, cout, h, w): time, TFLOP/s and algorithmic GB/s per layer shape (HIP events around every launch: sr_profile_*)."""
+grouped by (kernel, cin, cout, h, w): time, TFLOP/s and algorithmic GB/s per layer shape (HIP events around every launch: sr_profile_*).
+usage: python tools/c3_layers.py [recipe]     (recipe: the reference's own step — batch 32 of 32x32 patches, VGG discriminator, all bf16)"""
 import ctypes as C
 import os
 import sys
@@ -16,13 +17,18 @@ def main():
     from image_restoration_amd.models import build_model
     from image_restoration_amd.utils import synth
     from image_restoration_amd.utils.options import parse, set_random_seed
-    opt = parse(os.path.join(bench.ROOT, 'training_config', 'train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml'), bench.ROOT, is_train=True)
+    recipe = len(sys.argv) > 1 and sys.argv[1] == 'recipe'
+    yml = 'train_rrdbnet_esrgan_x4_mi355x.yml' if recipe else 'train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml'
+    opt = parse(os.path.join(bench.ROOT, 'training_config', yml), bench.ROOT, is_train=True)
     opt['dist'], opt['rank'], opt['world_size'], opt['num_gpu'] = False, 0, 1, 1
     opt['network_g']['compute_dtype'] = 'bf16'
-    opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True, compute_dtype='bf16')
+    if recipe:
+        opt['network_d']['compute_dtype'] = 'bf16'
+    else:
+        opt['network_d'] = dict(type='UNetDiscriminatorSN', num_in_ch=3, num_feat=64, skip_connection=True, compute_dtype='bf16')
     set_random_seed(opt['manual_seed'])
     model = build_model(opt)
-    b, lq = 32, 128
+    b, lq = (32, 32) if recipe else (32, 128)
     data = {'lq': torch.from_numpy(synth.uniform_input(100, (b, 3, lq, lq))).to(dev),
             'gt': torch.from_numpy(synth.uniform_input(200, (b, 3, 4 * lq, 4 * lq))).to(dev)}
     for it in range(2):
