@@ -109,6 +109,9 @@ class NetPack:
     def align_replicas(self, buffers_only=False):
         first_rank_broadcast(self.state_tensors(buffers_only))
         if not buffers_only:
+            from .. import hip_ops
+            hip_ops.invalidate_packs()   # (a collective does not bump torch's version counters: cached weight images are stale)
+        if not buffers_only:
             for m in (self.net, self.shadow):
                 if m is not None and hasattr(m, 'invalidate_packed'):
                     m.invalidate_packed()
