@@ -141,6 +141,11 @@ def test_rrdbnet_bf16_vs_reference_golden(golden):
     (512, 256, None, 0, 2, 8, 16, False),     # wide: 4 rows x 4 columns of 2x4 tile groups in one launch
     (288, 192, None, 0, 2, 8, 8, False),      # 3 cout rows x (2 batched columns + 1 odd cin tile)
     (2048, 128, None, 0, 32, 4, 4, False),    # 16 cin groups x 32 strips: more tile groups than the slab holds, cin chunks
+    # small images: the 1 / 2 k-step instances and several images per workgroup (a remainder in the last workgroup)
+    (512, 512, None, 0, 32, 8, 8, False),     # the VGG discriminator's deep layer at batch 32: 7 images per workgroup, 5 chunks
+    (64, 64, None, 0, 5, 8, 8, False),        # 2 x 2 tiles with 2 k-splits, one k-step per row
+    (32, 64, None, 0, 7, 16, 12, False),      # 4 k-splits: the one-k-step instance does not exist, two k-steps
+    (64, 32, None, 0, 9, 4, 4, False),        # 4x4 images, 9 of them
 ])
 def test_wgrad_bf16_matches_float64_of_rounded_inputs(cin, cout, first_seg, seg, n, h, w, ups):
     """dW, db in fp32 from bf16 x / dy: the products are exact in fp32, so the only error is fp32 summation order:
