@@ -2192,11 +2192,17 @@ extern "C" int sr_conv3x3_bf16(const sr_conv3x3_desc* d, void* stream_) {
   else
     tile = R4_W4;
   if (gc == 64) {
-    if (d->s2_channels > 0 && (tile == R16_W8 || tile == R32_W8)) {  // the strided convs of the discriminators
+    if (d->s2_channels > 0 && (tile == R16_W8 || tile == R32_W8 || tile == R8_W4 || tile == R16_W4)) {  // the strided convs of the discriminators
       p.s2_cpb = d->s2_channels / 16;
       p.s2_side = d->s2_side;
-      return tile == R16_W8 ? launch_h<2, 2, 8, false, true>(p, d->n, groups, stream, d)
-                            : launch_h<2, 4, 8, false, true>(p, d->n, groups, stream, d);
+      // (also on the 4-wave tiles: at patch size these layers are 8x8 and 4x4 maps of 2048 channels, and 5 of the 9 taps of every
+      // channel block are the zeros of the 3x3 embedding)
+      switch (tile) {
+        case R16_W8: return launch_h<2, 2, 8, false, true>(p, d->n, groups, stream, d);
+        case R32_W8: return launch_h<2, 4, 8, false, true>(p, d->n, groups, stream, d);
+        case R16_W4: return launch_h<2, 4, 4, false, true>(p, d->n, groups, stream, d);
+        default: return launch_h<2, 2, 4, false, true>(p, d->n, groups, stream, d);
+      }
     }
     switch (tile) {
       case R16_W8: return launch_h<2, 2, 8, false>(p, d->n, groups, stream, d);
