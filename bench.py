@@ -358,12 +358,20 @@ def secondary_workloads(net, args, world, rank, dev, dist, backend):
     guarded('c2_infer_bf16', infer_bf16)
     guarded('c5_tiled_4k_bf16', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='bf16', steps=2, warmup=1,
                                                       tile_batch=args.tile_batch, profile=True))
-    guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=1, warmup=0,
+    guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=2, warmup=0,
                                                       tile_batch=args.tile_batch, profile=False))
     net.set_compute_dtype(args.dtype)
     guarded('c3_train_step', lambda: measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml',
                                                    dtype='bf16', disc='unet', disc_dtype='bf16', batch=32, lq=128, steps=3, warmup=1,
                                                    profile=True))
+    # the reference's own recipe (train_ESRGAN_x4.yml:24,51-54: 128x128 ground-truth patches = 32x32 LR, VGGStyleDiscriminator128),
+    # all bf16 and all fp32: what `python bench.py --mode train --lq 32 --batch 32 [--dtype bf16 --disc-dtype bf16]` prints
+    guarded('recipe_train_step_bf16', lambda: measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x.yml',
+                                                            dtype='bf16', disc='vgg', disc_dtype='bf16', batch=32, lq=32, steps=20,
+                                                            warmup=5, profile=False))
+    guarded('recipe_train_step_fp32', lambda: measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x.yml',
+                                                            dtype='fp32', disc='vgg', disc_dtype=None, batch=32, lq=32, steps=10,
+                                                            warmup=3, profile=False))
     return out
 
 
