@@ -827,601 +827,13 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 // A tile's workgroup waits for its 8 neighbours at every hand-off.  Tiles are numbered image-major, row-major over the whole batch and
 // workgroup b of a grid of G <= CUs takes tiles b, b + G, ... in increasing order, so the tiles in flight are a window of that order
 // (see the kernel): the host only asks for G >= 6 tiles_x + 2 and falls back to the chain kernel otherwise.
-#include "fused_sched.h"
-namespace fz {
-struct WTab {
-  unsigned v[MAXP];
-};
-constexpr WTab make_wtab() {
-  WTab t{};
-  for (int i = 0; i < MAXP; ++i) t.v[i] = i < kS.ngroups * 8 ? kS.wtab[i] : kS.wtab[0];
-  return t;
-}
-__device__ const WTab kWTabDev = make_wtab();
-
-struct FusedParams {
-  ConvParamsH lv[5];   // first member: conv_params() reads it from the kernel argument segment
-  unsigned wdelta[5];  // byte offset of conv k's packed image from wbase
-  const char* wbase;
-  unsigned wspan;      // bytes covered by the five images from wbase
-  int n, tiles_x, tiles_y;       // images, tile grid of an image
-  int* head;                     // ticket counter of this launch (zero before it): tiles are claimed in image-major, row-major order
-  int* done;
-  int* abort;
-  int epoch;
-  long long* dbg;
-  // LEAN kernel (the forward dense block: conv1-4 = bias + LeakyReLU(slope), conv5 = alpha5 (conv + bias) + beta1 res1 [+ beta2 res2])
-  float slope, alpha5, beta1, beta2;
-  char* out5;  // conv5's destination, residual sources: CB16 tensors of 64 channels over the same pixel grid
-  const char* res1;
-  const char* res2;  // may be null
-  long long out5_nb, res1_nb, res2_nb;
-  // lean transposed block: conv1-4 = lrelu'(mask) * conv (mask: the forward activation, 32 channels), conv5 as above without bias
-  const char* mask[4];
-  long long mask_nb;
-  float mask_slope;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
-
-#ifndef SR_FZ_DRAIN
-#define SR_FZ_DRAIN 0  // development: 1 = every counted wait becomes vmcnt(0)
-#endif
-template <int K>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR_FZ_DRAIN ? 0 : K) : "memory");
-}
-
-typedef __attribute__((address_space(3))) int* lds_int_p;
-typedef __attribute__((address_space(3))) void* lds_void_p;
-
-struct Env {
-  char* smem;
-  lds_int_p ctl;       // LDS word: a dependency wait timed out
-  int wave, tid;
-  int n, tile, x0, y0;  // image, tile of the batch, first column / row of the tile
-  int next;             // the workgroup's next tile (ticket), known from the hand-over step on
-  unsigned claimed;     // thread 0: the ticket as the atomic returns it
-  lds_int_p nextp;      // LDS word through which thread 0 hands the ticket to the other waves
-  unsigned xpk[5];     // per tile piece of this wave: pixel row | column << 8 | swizzle bit << 16 | inside the tile << 17
-  unsigned wvo;        // lane offset inside a weight piece (bank swizzle)
-  unsigned fvo;        // wave 0: lane offset of this lane's neighbour flag in the image's row of progress words (lanes 0-8; else out of range)
-  unsigned plane_b;
-  int W, H;            // image width, height
-  const char* xin;     // the image's concat buffer
-  int xl[3];           // LDS byte offset of this lane's pixel operand at tap column dx (tile row of the wave)
-  int wlane;           // LDS byte offset of this lane's weight operand inside a piece
-  long long* dbg;
-};
-
-// Two chunks of a tile = 40 pieces of 1 KB, five per wave.  What depends on the lane only (row and column of its pixel inside the
-// tile, bank-swizzle bit, padding) is packed into one register per piece at kernel start (Env::xpk); the byte offsets inside a
-// channel-block plane (padding -> out of range) are finished at every issue from the tile's origin: ~12 vector instructions per
-// piece.  (Unpacked, hipcc hoisted the lane-only parts out of the tile loop into ~20 registers and spilled; recomputed from the
-// lane id at every issue they cost ~800 cycles in front of the step's MFMAs, six times per tile.)
-template <int AUX>
-__device__ __forceinline__ void issue_tile_pair(const Env& e, const __amdgpu_buffer_rsrc_t x_rs, const int tb0, const int cb0, const int x0,
-                                                const int y0) {
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int u = r * NW + e.wave;
-    const int ci = u >= XU ? 1 : 0, pc = u - ci * XU;
-    unsigned pk = e.xpk[r];
-    asm volatile("" : "+v"(pk));
-    const int gy = y0 - 1 + (int)(pk & 0xffu), gx = x0 - 1 + (int)((pk >> 8) & 0xffu);
-    const bool valid = (pk >> 17) != 0u && gy >= 0 && gy < e.H && gx >= 0 && gx < e.W;
-    const unsigned vo = valid ? (unsigned)((gy * e.W + gx) * 32) + ((pk >> 12) & 16u) : 0xfffffff0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void_p)(e.smem + LDS_X0 + (tb0 + ci) * XBUF + pc * 1024), 16, vo,
-                                             (unsigned)(cb0 + ci) * e.plane_b, 0, AUX);
-  }
-}
-
-template <int Q>
-__device__ __forceinline__ void issue_wgroup(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
-  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(*(const lds_int_p)(e.smem + LDS_WTAB + (Q * 8 + e.wave) * 4));
-  constexpr int base = (Q * 8) % RING;
-  int slot = base + e.wave;
-  if constexpr (base + 7 >= RING) slot = slot >= RING ? slot - RING : slot;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_p)(e.smem + LDS_W0 + slot * 1024), 16, e.wvo, so, 0, 0);
-}
-template <int Q, int Q1>
-__device__ __forceinline__ void issue_wgroups(const Env& e, const __amdgpu_buffer_rsrc_t w_rs) {
-  if constexpr (Q < Q1) {
-    issue_wgroup<Q>(e, w_rs);
-    issue_wgroups<Q + 1, Q1>(e, w_rs);
-  }
-}
-
-// the MFMAs of step S: units (tap column, group) in order, three weight fragments (tap rows) per unit.  Operands are read ahead of
-// their MFMAs — weight fragments AR-1 fragments ahead through a ring of AR, the pixel rows of the next tap column during the current
-// column's last unit — and the read-ahead runs across the step barrier: the barrier then meets waves whose next MFMAs can issue at once
-// (the barrier of step S-1 has already said that step S's weight pieces and tile have landed).
-struct Ops {
-  bf16x8 bx[2][PT + 2];  // pixel operands of a tap column, by parity of the column count
-  bf16x8 a[AR];          // weight fragments, by fragment count modulo AR
-};
-template <int S>
-__device__ __forceinline__ void load_bx(const Env& e, Ops& o, const int dxi) {  // tap column dx0 + dxi of step S
-  constexpr StepD d = kS.st[S];
-  const char* xs = e.smem + LDS_X0 + d.tb * XBUF + e.xl[d.dx0 + dxi];
-#pragma unroll
-  for (int r = 0; r < PT + 2; ++r) o.bx[(d.dc0 + dxi) & 1][r] = *(const bf16x8*)(xs + r * XROW * 32);
-}
-template <int S>
-__device__ __forceinline__ void load_a(const Env& e, Ops& o, const int lf) {  // fragment lf = 3 unit + tap row of step S
-  constexpr StepD d = kS.st[S];
-  o.a[(3 * d.uc0 + lf) % AR] = *(const bf16x8*)(e.smem + LDS_W0 + e.wlane + ((d.wp0 + lf) % RING) * 1024);
-}
-template <int S, class Issue>
-__device__ __forceinline__ void compute_step(const Env& e, f32x16 (&acc)[NG][PT], Ops& o, Issue&& issue) {
-  constexpr StepD d = kS.st[S];
-  constexpr int NU = d.ndx * d.ng, NF = 3 * NU;
-  constexpr bool next_pre = S + 1 < kS.nsteps && kS.st[S + 1 < kS.nsteps ? S + 1 : S].pre;
-  if constexpr (!d.pre) {
-    load_bx<S>(e, o, 0);
-#pragma unroll
-    for (int f = 0; f < AR - 1; ++f) load_a<S>(e, o, f);
-  }
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int dxi = u / d.ng, g = d.g0 + u % d.ng;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int lf = 3 * u + dy, nf = lf + AR - 1;
-      if (nf < NF)
-        load_a<S>(e, o, nf);
-      else if constexpr (next_pre)
-        load_a<(next_pre ? S + 1 : S)>(e, o, nf - NF);
-      if (dy == 0 && (u + 1) % d.ng == 0) {  // last unit of this tap column: the next column's pixel rows
-        if (u + 1 < NU)
-          load_bx<S>(e, o, dxi + 1);
-        else if constexpr (next_pre)
-          load_bx<(next_pre ? S + 1 : S)>(e, o, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < PT; ++r)
-        acc[g][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[(3 * d.uc0 + lf) % AR], o.bx[(d.dc0 + dxi) & 1][r + dy], acc[g][r], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (lf == 0) {
-        issue();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-}
-
-// conv k's parameters, read from the kernel argument segment where they are used: as plain kernel arguments the ~140 scalars of the
-// five epilogues are loaded at the top of the kernel and spilled (the offset passes through an empty asm so that the loads cannot be
-// hoisted)
-__device__ __forceinline__ ConvParamsH conv_params(int k) {
-  unsigned off = (unsigned)(k * sizeof(ConvParamsH));  // FusedParams::lv is the first member
-  asm volatile("" : "+s"(off));
-  typedef const __attribute__((address_space(4))) unsigned* kernarg_words;
-  kernarg_words src = (kernarg_words)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
-  static_assert(sizeof(ConvParamsH) % 4 == 0, "ConvParamsH is copied word by word");
-  unsigned words[sizeof(ConvParamsH) / 4];
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(ConvParamsH) / 4; ++i) words[i] = src[i];
-  ConvParamsH r;
-  __builtin_memcpy(&r, words, sizeof(r));
-  return r;
-}
-
-// ---- epilogues of the LEAN (forward) kernel: one basic block each, no vector-memory loads.  Per element the operations and their
-// order are those of epilogue_cb16 (bias add, LeakyReLU, scale, residual scale-adds, bf16 conversion), with two exact shortcuts:
-// LeakyReLU as max(v, v * slope) for 0 <= slope <= 1 (the same value for every input, signed zeros and NaNs included) and no
-// multiplication by a scale of exactly 1.
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void swap_halves4(u32x4v& t) {  // t[0..1] of the upper lanes <-> t[2..3] of the lower lanes
-  auto r0 = __builtin_amdgcn_permlane32_swap(t[0], t[2], false, false);
-  auto r1 = __builtin_amdgcn_permlane32_swap(t[1], t[3], false, false);
-  t = u32x4v{r0[0], r1[0], r0[1], r1[1]};
-}
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 t = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ unsigned tile_lane_offset(const Env& e) {  // byte offset of (first row of the wave, this lane's column, half)
-  const int lane = e.tid & 63, x = e.x0 + (lane & 31);
-  return x < e.W ? (unsigned)(((e.y0 + e.wave * PT) * e.W + x) * 32 + (lane >> 5) * 16) : 0xfffffff0u;
-}
-
-template <int K>  // conv K+1, K = 0..3: x_(K+1) = LeakyReLU(acc + bias) into blocks 4+2K, 5+2K of the concat buffer, write-through
-__device__ __forceinline__ void epi_mid_lean(const Env& e, f32x16 (&acc)[PT], const __amdgpu_buffer_rsrc_t x_rs, const float slope) {
-  typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
-  const int h = (e.tid >> 5) & 1;
-  f32x4 bias[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) bias[g] = *(lds_f4_p)(e.smem + LDS_BIAS + K * 256 + (g * 8 + h * 4) * 4);
-  const unsigned vo = tile_lane_offset(e);
-#pragma unroll
-  for (int r = 0; r < PT; ++r)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float t = acc[r][m * 8 + i] + bias[2 * m + (i >> 2)][i & 3];
-        v[i] = __builtin_fmaxf(t, t * slope);
-      }
-      u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-      swap_halves4(o);
-      // a global store behind store16's asm (store + two wait states): as a buffer store with a scalar offset — the form the
-      // compiler's hazard recognizer treats as safe — the next vector instruction overwrote the store's first data register in
-      // ~1 of 500 tiles (second wave of a SIMD; measured)
-      if (vo != 0xfffffff0u) store16((char*)e.xin + (size_t)(4 + 2 * K + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, true);
-    }
-}
-
-struct MaskRegs {
-  u32x4v m[PT][2];  // [row][channel block]: the forward activation whose sign gates conv k's output, fetched one step ahead
-};
-__device__ __forceinline__ void fetch_mask(const Env& e, MaskRegs& M, const __amdgpu_buffer_rsrc_t m_rs) {
-  const unsigned vo = tile_lane_offset(e);
-#pragma unroll
-  for (int r = 0; r < PT; ++r)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-      M.m[r][m] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, vo == 0xfffffff0u ? vo : vo + (unsigned)(r * e.W * 32), (unsigned)m * e.plane_b, 0);
-}
-template <int K>  // transposed block, conv K+1: dY = (mask > 0 ? 1 : mask_slope) * acc into blocks 4+2K, 5+2K of D, write-through
-__device__ __forceinline__ void epi_mid_mask(const Env& e, f32x16 (&acc)[PT], MaskRegs& M, const float mask_slope) {
-  const unsigned vo = tile_lane_offset(e);
-#pragma unroll
-  for (int r = 0; r < PT; ++r)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      u32x4v mm = M.m[r][m];
-      swap_halves4(mm);
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned w = mm[i >> 1];
-        const float t = acc[r][m * 8 + i];
-        v[i] = __builtin_bit_cast(float, (i & 1) ? (w & 0xffff0000u) : (w << 16)) > 0.f ? t : t * mask_slope;
-      }
-      u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-      swap_halves4(o);
-      if (vo != 0xfffffff0u) store16((char*)e.xin + (size_t)(4 + 2 * K + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, true);
-    }
-}
-
-struct ResRegs {
-  u32x4v r1[2][PT][2], r2[2][PT][2];  // [cout tile][row][channel block]: the residual sources of conv5's epilogue, fetched ahead
-};
-__device__ __forceinline__ void fetch_residuals(const Env& e, ResRegs& R, const __amdgpu_buffer_rsrc_t r1_rs, const __amdgpu_buffer_rsrc_t r2_rs) {
-  const unsigned vo = tile_lane_offset(e);
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int r = 0; r < PT; ++r)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const unsigned v = vo == 0xfffffff0u ? vo : vo + (unsigned)(r * e.W * 32);
-        R.r1[c][r][m] = __builtin_amdgcn_raw_buffer_load_b128(r1_rs, v, (unsigned)(c * 2 + m) * e.plane_b, 0);
-        R.r2[c][r][m] = __builtin_amdgcn_raw_buffer_load_b128(r2_rs, v, (unsigned)(c * 2 + m) * e.plane_b, 0);  // empty descriptor: zeros
-      }
-}
-// conv5: out = alpha (acc + bias) + beta1 res1 [+ beta2 res2]
-template <bool HAS_BIAS>
-__device__ __forceinline__ void epi_last_lean(const Env& e, f32x16 (&acc)[2][PT], ResRegs& R, char* out, const float alpha,
-                                              const float beta1, const float beta2, const bool has_res2) {
-  typedef const __attribute__((address_space(3))) f32x4* lds_f4_p;
-  const int h = (e.tid >> 5) & 1;
-  const unsigned vo = tile_lane_offset(e);
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    f32x4 bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = *(lds_f4_p)(e.smem + LDS_BIAS + 4 * 256 + (c * 32 + g * 8 + h * 4) * 4);
-#pragma unroll
-    for (int r = 0; r < PT; ++r)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        u32x4v a = R.r1[c][r][m], b = R.r2[c][r][m];
-        swap_halves4(a);
-        swap_halves4(b);
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float t = acc[c][r][m * 8 + i];
-          if constexpr (HAS_BIAS) t += bias[2 * m + (i >> 2)][i & 3];
-          t *= alpha;
-          const unsigned wa = a[i >> 1], wb = b[i >> 1];
-          t += beta1 * __builtin_bit_cast(float, (i & 1) ? (wa & 0xffff0000u) : (wa << 16));
-          const float t2 = t + beta2 * __builtin_bit_cast(float, (i & 1) ? (wb & 0xffff0000u) : (wb << 16));
-          v[i] = has_res2 ? t2 : t;
-        }
-        u32x4v o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-        swap_halves4(o);
-        if (vo != 0xfffffff0u) store16(out + (size_t)(c * 2 + m) * e.plane_b + vo + (unsigned)(r * e.W * 32), o, false);
-      }
-  }
-}
-
-// the LEAN kernel's scalars, read from the kernel argument segment where they are used (see conv_params)
-template <class T>
-__device__ __forceinline__ T kernarg_at(unsigned off) {
-  asm volatile("" : "+s"(off));
-  typedef const __attribute__((address_space(4))) unsigned* kernarg_words;
-  kernarg_words src = (kernarg_words)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
-  static_assert(sizeof(T) % 4 == 0, "copied word by word");
-  unsigned words[sizeof(T) / 4];
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; ++i) words[i] = src[i];
-  T r;
-  __builtin_memcpy(&r, words, sizeof(r));
-  return r;
-}
-
-__device__ __forceinline__ void stamp(const Env& e, int i) {
-  if (e.dbg && e.tid == 0) e.dbg[i] = __builtin_readcyclecounter();
-}
-
-template <int S, int MODE>
-__device__ __forceinline__ bool do_step(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                        const __amdgpu_buffer_rsrc_t w_rs) {
-  constexpr StepD d = kS.st[S];
-  // the lane address bases pass through an empty asm at every step: derived addresses (tile buffer + column offset ...) are then
-  // computed where they are used instead of being hoisted out of the round loop into two dozen permanently live registers
-  asm volatile("" : "+v"(e.xl[0]), "+v"(e.xl[1]), "+v"(e.xl[2]), "+v"(e.wlane));
-  if constexpr (d.publish > 0) stamp(e, 2 + 8 * (d.publish - 1) + 2);
-  if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 6);
-  if constexpr (d.tile_in > 0) {  // the neighbours' conv `tile_in` must be published before its tile is fetched
-    stamp(e, 2 + 8 * (d.tile_in - 1) + 4);
-    if (e.wave == 0) {
-      wait_vm<step_Kflag<MODE, S>()>();  // the flag fetch of a few steps ago has landed
-      bool gave_up = false;
-      const int lane = e.tid & 63;
-      unsigned fvo = e.fvo;
-      asm volatile("" : "+v"(fvo));  // (the slow path's address is computed here, not kept in registers — or scratch — from the tile's start)
-      if (fvo != 0xfffffff0u) {
-        const int want = P.epoch + d.tile_in;
-        const int* flag_ptr = P.done + e.n * (P.tiles_x * P.tiles_y) + (fvo >> 2);
-        int v = *(volatile lds_int_p)(e.smem + LDS_FLAGS + lane * 4), spins = 0;
-        while (v < want) {
-          __builtin_amdgcn_s_sleep(2);
-          v = flag_load(flag_ptr);
-          if ((++spins & 255) == 0 && (spins > (1 << 22) || flag_load(P.abort))) {
-            __hip_atomic_store(P.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gave_up = true;
-            break;
-          }
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(gave_up)) {
-        if (lane == 0) *(volatile lds_int_p)e.ctl = 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-  }
-  wait_vm<step_K<MODE, S>()>();
-  __builtin_amdgcn_s_barrier();
-  if constexpr (S > 0 && kS.st[S > 0 ? S - 1 : 0].claim == 2) e.next = __builtin_amdgcn_readfirstlane(*(volatile lds_int_p)e.nextp);
-  if constexpr (S == 0) stamp(e, 1);
-  if constexpr (d.tile_in > 0) stamp(e, 2 + 8 * (d.tile_in - 1) + 5);
-  if constexpr (d.first_of_in > 0) stamp(e, 2 + 8 * (d.first_of_in - 1) + 7);
-  if constexpr (d.publish > 0) {  // every wave's stores of conv `publish` have landed (K covers them)
-    if (e.tid == 0) __hip_atomic_store(P.done + e.tile, P.epoch + d.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stamp(e, 2 + 8 * (d.publish - 1) + 3);
-  }
-  if constexpr (d.tile_in > 0) {
-    if (*(volatile lds_int_p)e.ctl) return false;
-  }
-  // Everything this step issues to memory, in the order the counted waits assume.  It runs BEHIND the step's first MFMAs (operands
-  // read ahead), so its scalar / vector work — offset table reads, lane offsets of tile pieces, descriptors — sits in the matrix
-  // pipe's shadow instead of between the barrier and the first MFMA.
-  auto issue_all = [&]() {
-  if constexpr (d.claim == 2) {  // thread 0 hands its ticket to the other waves (they read it behind the next barrier)
-    if (e.tid == 0) {
-      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(e.claimed) : "n"(step_Kclaim<MODE, S>()) : "memory");
-      *(volatile lds_int_p)e.nextp = (int)e.claimed;
-    }
-  }
-  if constexpr (d.tile_in > 0)
-    issue_tile_pair<SC1>(e, x_rs, in_tb0(d.tile_in), in_cb0(d.tile_in), e.x0, e.y0);  // agent scope: written by other workgroups of this launch
-  issue_wgroups<d.q0, d.q1>(e, w_rs);
-  if constexpr (d.nx_tile > 0) {  // the workgroup's next tile (behind the last one: an empty descriptor = zeros, no traffic)
-    const int T = P.tiles_x * P.tiles_y;
-    const bool more = e.next < P.n * T;
-    const int nn = more ? e.next / T : 0, tn = more ? e.next - nn * T : 0, tyn = tn / P.tiles_x;
-    const char* in0 = kernarg_at<const char*>(offsetof(ConvParamsH, in));
-    const long long nb0 = kernarg_at<long long>(offsetof(ConvParamsH, in_nb));
-    issue_tile_pair<0>(e, make_rsrc(in0 + nn * nb0, more ? 12u * e.plane_b : 0u), 2 * (d.nx_tile - 1), 2 * (d.nx_tile - 1),
-                       (tn - tyn * P.tiles_x) * 32, tyn * TH);
-  }
-  issue_wgroups<d.nx_q0, d.nx_q1>(e, w_rs);
-  if constexpr (d.flag_in > 0) {
-    if (e.wave == 0) {
-      const int T = P.tiles_x * P.tiles_y;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(P.done + e.n * T, (unsigned)T * 4u), (lds_void_p)(e.smem + LDS_FLAGS), 4, e.fvo, 0, 0, SC1);
-    }
-  }
-  if constexpr (MODE != 0 && d.first_of_in == 4) {  // conv5's residual sources: 16 loads per wave that land under the last input's MFMAs
-    const char* r1 = kernarg_at<const char*>(offsetof(FusedParams, res1));
-    const char* r2 = kernarg_at<const char*>(offsetof(FusedParams, res2));
-    const long long nb1 = kernarg_at<long long>(offsetof(FusedParams, res1_nb)), nb2 = kernarg_at<long long>(offsetof(FusedParams, res2_nb));
-    __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
-    fetch_residuals(e, R, make_rsrc(r1 + e.n * nb1, 4u * e.plane_b), make_rsrc(r2 ? r2 + e.n * nb2 : r1, r2 ? 4u * e.plane_b : 0u));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if constexpr (MODE == 2) {  // the mask of the conv that completes with this step or the next
-    constexpr int k = mask_conv_at(kS, S);
-    if constexpr (k >= 1) {
-      const char* mp = kernarg_at<const char*>(offsetof(FusedParams, mask) + (k - 1) * sizeof(const char*));
-      const long long nbm = kernarg_at<long long>(offsetof(FusedParams, mask_nb));
-      __builtin_amdgcn_sched_barrier(0);  // the counted waits assume this place in the issue order
-      fetch_mask(e, M, make_rsrc(mp + e.n * nbm, 2u * e.plane_b));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if constexpr (d.claim == 1) {
-    // The ticket of the workgroup's next tile: a returning atomic by thread 0, as inline asm so that nothing waits for it here (a
-    // builtin atomic is followed by vmcnt(0) at once: ~4 thousand cycles behind this step's agent-scope tile loads, and the whole
-    // workgroup behind that at the next barrier).  Its value is consumed three steps later behind a counted wait.
-    if (e.tid == 0) {
-      unsigned zero = 0u, one = 1u;
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(e.claimed) : "v"(zero), "v"(one), "s"(P.head) : "memory");
-    }
-  }
-  };
-  if constexpr (d.post > 0 && d.post < 5) stamp(e, 2 + 8 * (d.post - 1));  // last step of conv `post` runs
-  if constexpr (d.post == 5) stamp(e, 40);
-#pragma unroll
-  for (int g = 0; g < NG; ++g)
-    if (d.zero_mask >> g & 1) {
-#pragma unroll
-      for (int r = 0; r < PT; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[g][r][i] = 0.f;
-    }
-  compute_step<S>(e, acc, o, issue_all);
-  typedef const __attribute__((address_space(3))) float* lds_float_p;
-  if constexpr (MODE == 1 && d.post > 0 && d.post < 5) {
-    epi_mid_lean<d.post - 1>(e, acc[d.post - 1], x_rs, kernarg_at<float>(offsetof(FusedParams, slope)));
-    stamp(e, 2 + 8 * (d.post - 1) + 1);
-  } else if constexpr (MODE == 2 && d.post > 0 && d.post < 5) {
-    epi_mid_mask<d.post - 1>(e, acc[d.post - 1], M, kernarg_at<float>(offsetof(FusedParams, mask_slope)));
-    stamp(e, 2 + 8 * (d.post - 1) + 1);
-  } else if constexpr (MODE != 0 && d.post == 5) {
-    stamp(e, 41);
-    char* o5 = kernarg_at<char*>(offsetof(FusedParams, out5));
-    const long long nbo = kernarg_at<long long>(offsetof(FusedParams, out5_nb));
-    epi_last_lean<MODE == 1>(e, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), R, o5 + e.n * nbo,
-                  kernarg_at<float>(offsetof(FusedParams, alpha5)), kernarg_at<float>(offsetof(FusedParams, beta1)),
-                  kernarg_at<float>(offsetof(FusedParams, beta2)), kernarg_at<const char*>(offsetof(FusedParams, res2)) != nullptr);
-  } else if constexpr (d.post > 0 && d.post < 5) {
-    const ConvParamsH lp = conv_params(d.post - 1);
-    epilogue_cb16<1, PT, true, true>(lp, reinterpret_cast<f32x16(&)[1][PT]>(acc[d.post - 1]), 0, e.n, e.x0 + (e.tid & 31),
-                                     e.y0 + e.wave * PT, (e.tid >> 5) & 1,
-                                     (lds_float_p)(e.smem + LDS_BIAS + (d.post - 1) * 256));
-    stamp(e, 2 + 8 * (d.post - 1) + 1);
-  } else if constexpr (d.post == 5) {
-    stamp(e, 41);
-    const ConvParamsH lp = conv_params(4);
-    epilogue_cb16<2, PT, false, true>(lp, reinterpret_cast<f32x16(&)[2][PT]>(acc[4]), 0, e.n, e.x0 + (e.tid & 31), e.y0 + e.wave * PT,
-                                      (e.tid >> 5) & 1,
-                                      (lds_float_p)(e.smem + LDS_BIAS + 4 * 256));
-  }
-  return true;
-}
-
-template <int S, int MODE>
-__device__ __forceinline__ bool run_steps(Env& e, f32x16 (&acc)[NG][PT], Ops& o, ResRegs& R, MaskRegs& M, const FusedParams& P, const __amdgpu_buffer_rsrc_t x_rs,
-                                          const __amdgpu_buffer_rsrc_t w_rs) {
-  if constexpr (S < kS.nsteps) {
-    if (!do_step<S, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) return false;
-    return run_steps<S + 1, MODE>(e, acc, o, R, M, P, x_rs, w_rs);
-  } else {
-    return true;
-  }
-}
-
-}  // namespace fz
-
-template <int MODE>  // epilogues: 0 generic (epilogue_cb16), 1 lean forward block, 2 lean transposed block
-__global__ __launch_bounds__(512, 2) void rdb_fused_bf16_kernel(const fz::FusedParams P) {
-  using namespace fz;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_ctl;
-  Env e;
-  e.smem = smem;
-  e.ctl = (lds_int_p)&s_ctl;
-  e.tid = threadIdx.x;
-  const int lane = e.tid & 63;
-  e.wave = __builtin_amdgcn_readfirstlane(e.tid >> 6);
-  e.dbg = P.dbg ? P.dbg + (size_t)blockIdx.x * 64 : nullptr;
-  const int j = lane & 31, h = lane >> 5;
-  const ConvParamsH& p0 = P.lv[0];
-  e.plane_b = (unsigned)(p0.H * p0.W * 32);
-  e.W = p0.W;
-  e.H = p0.H;
-  e.wvo = (lane ^ ((lane >> 4) & 1)) * 16;
-  e.wlane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);
-  const int xrow0 = ((e.wave * PT) * XROW + j) * 32;
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) e.xl[dx] = xrow0 + dx * 32 + ((h ^ (((j + dx) >> 3) & 1)) * 16);
-  if (e.tid < 480) {  // source offset of every weight piece: the static table + where this block's five images are
-    const unsigned t = kWTabDev.v[e.tid];
-    const unsigned k = t >> 28;
-    const unsigned dlt = k == 0 ? P.wdelta[0] : k == 1 ? P.wdelta[1] : k == 2 ? P.wdelta[2] : k == 3 ? P.wdelta[3] : P.wdelta[4];
-    ((unsigned*)(smem + LDS_WTAB))[e.tid] = dlt + (t & 0x0fffffffu);
-  }
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int u = r * NW + e.wave;
-    const int pc = u >= XU ? u - XU : u;
-    const int q = pc * 64 + lane;
-    const int pix = q >> 1, half = q & 1;
-    const int row = pix / XROW, col = pix - row * XROW;
-    e.xpk[r] = (unsigned)row | (unsigned)col << 8 | (unsigned)(half ^ ((col >> 3) & 1)) << 16 | (pix < XPIX ? 1u << 17 : 0u);
-  }
-  const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(P.wbase, P.wspan);
-  if (e.tid == 0) s_ctl = 0;
-  if (e.tid < 5 * 64) {  // the five packed biases (conv1-4: 32 floats, conv5: 64; zeros when a conv has none)
-    const int k = e.tid >> 6, i = e.tid & 63;
-    const float* b = P.lv[k].bias;
-    ((float*)(smem + LDS_BIAS))[e.tid] = (b && i < (k < 4 ? 32 : 64)) ? b[i] : 0.f;
-  }
-  const int T = P.tiles_x * P.tiles_y;
-  if (e.dbg && e.tid == 0) {  // absolute clocks (comparable inside an XCD) of this workgroup's start ...
-    e.dbg[60] = __builtin_readcyclecounter();
-    e.dbg[62] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
-  }
-  // Tiles are claimed from a counter, in image-major, row-major order over the whole batch, and a workgroup claims its next tile only
-  // when the current one depends on nobody any more.  The tiles in flight are then a window of that order as wide as the number of
-  // RESIDENT workgroups, whatever that number is: a tile's dependencies (its 8 neighbours, at most one tile row ahead, per conv)
-  // are running or finished as long as ~5 rows of tiles fit the window (the host asks for 6 tiles_x + 2 <= grid).
-  __shared__ int s_next;
-  e.nextp = (lds_int_p)&s_next;
-  e.claimed = 0u;
-  if (e.tid == 0) s_next = atomicAdd(P.head, 1);
-  __syncthreads();  // also: s_ctl, the biases and the weight-offset table are set
-  int cur = s_next;
-  const int NT = P.n * T;
-  for (int round = 0;; ++round) {
-    if (cur >= NT) break;
-    e.n = cur / T;
-    const int t = cur - e.n * T;
-    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-    e.x0 = tx * 32;
-    e.y0 = ty * TH;
-    e.tile = cur;
-    e.next = NT;
-    {  // this lane's neighbour tile (wave 0, lanes 0-8): its progress word inside the image's T words
-      int nb = -1;
-      if (e.wave == 0 && lane < 9) {
-        const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
-        if (ny >= 0 && ny < P.tiles_y && nx >= 0 && nx < P.tiles_x) nb = ny * P.tiles_x + nx;
-      }
-      e.fvo = nb >= 0 ? (unsigned)nb * 4u : 0xfffffff0u;
-    }
-    e.xin = p0.in + (long long)e.n * p0.in_nb;
-    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(e.xin, 12u * e.plane_b);
-    // (the x chunks and the first weight groups of the next tile are issued during this one — make_sched: nx_tile, nx_q* —, the same
-    // instructions in the same order before the first tile)
-    if (round == 0) {
-      issue_tile_pair<0>(e, x_rs, 0, 0, e.x0, e.y0);
-      issue_tile_pair<0>(e, x_rs, 2, 2, e.x0, e.y0);
-      issue_wgroups<0, kS.q_ahead>(e, w_rs);
-    }
-    stamp(e, 0);
-    issue_wgroups<kS.q_ahead, kS.q_init>(e, w_rs);
-    f32x16 acc[NG][PT];
-    Ops o;
-    ResRegs R;
-    MaskRegs M;
-    if (!run_steps<0, MODE>(e, acc, o, R, M, P, x_rs, w_rs)) break;
-    stamp(e, 42);
-    cur = e.next;
-  }
-  if (e.dbg && e.tid == 0) e.dbg[61] = __builtin_readcyclecounter();  // ... and end
-  fz::wait_vm<0>();  // the read-ahead behind the last round lands before the workgroup's LDS is released
-}
+#define SR_FZ_NS fz
+#define SR_FZ_PT 2
+#define SR_FZ_KERNEL rdb_fused_bf16_kernel
+#include "fused_block.inc"
+#undef SR_FZ_NS
+#undef SR_FZ_PT
+#undef SR_FZ_KERNEL
 
 // ------------------------------------------------------------------------------------------------ streaming conv (Cin <= 64)
 // The large-image layers with few input channels — conv_hr / the upsampling convs of the generator's head, the U-Net

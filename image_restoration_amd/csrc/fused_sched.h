@@ -1,9 +1,15 @@
 // Static schedule of the fused dense-block kernel (rdb_fused_bf16_kernel, conv_bf16.hip): plain constexpr C++17, no HIP — the kernel
 // includes it, and tests/test_fused_schedule.py compiles it with g++ and replays the schedule against an independent model of the
 // issue order (what each counted wait guarantees, ring-slot and tile-buffer lifetimes).
-#pragma once
-namespace fz {
-constexpr int NW = 8, PT = 2, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+// (no include guard: conv_bf16.hip includes it once per tile height through fused_block.inc)
+#ifndef SR_FZ_NS
+#define SR_FZ_NS fz
+#endif
+#ifndef SR_FZ_PT
+#define SR_FZ_PT 2
+#endif
+namespace SR_FZ_NS {
+constexpr int NW = 8, PT = SR_FZ_PT, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
 constexpr int XU = 20, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer (18 x 34 pixels x 32 B, rounded up)
 constexpr int RING = 36;                            // weight ring, pieces
 constexpr int LDS_W0 = 0;                           // the ring first: its reads then need no address arithmetic (16-bit offsets)
@@ -258,4 +264,4 @@ template <int MODE, int S>
 constexpr int step_Kflag() { return MODE == 0 ? kS.st[S].Kflag : MODE == 1 ? kSL.st[S].Kflag : kSB.st[S].Kflag; }
 template <int MODE, int S>
 constexpr int step_Kclaim() { return MODE == 0 ? kS.st[S].Kclaim : MODE == 1 ? kSL.st[S].Kclaim : kSB.st[S].Kclaim; }
-}  // namespace fz
+}  // namespace SR_FZ_NS
