@@ -20,6 +20,8 @@
 // two 16-byte halves of pixel / cout number c in swapped order when bit 3 of c is set: lanes 8 apart then fall on
 // different slots and every group covers all 64 banks.  The swap is applied by the LDS-DMA source address (the lane that
 // fills unit q fetches the half that belongs there), so global reads stay whole 32-byte pixels.
+#include <cstring>
+
 #include "sr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -834,6 +836,15 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 #undef SR_FZ_NS
 #undef SR_FZ_PT
 #undef SR_FZ_KERNEL
+// ... and on 8-row tiles (one row per wave), for launches whose 16-row tiles would leave most of the chip idle: a batch of 32 x 32
+// training patches is 64 tiles of 16 x 32 on 256 CUs, and a tile's five convs are one dependency chain
+#define SR_FZ_NS fz8
+#define SR_FZ_PT 1
+#define SR_FZ_KERNEL rdb_fused8_bf16_kernel
+#include "fused_block.inc"
+#undef SR_FZ_NS
+#undef SR_FZ_PT
+#undef SR_FZ_KERNEL
 
 // ------------------------------------------------------------------------------------------------ streaming conv (Cin <= 64)
 // The large-image layers with few input channels — conv_hr / the upsampling convs of the generator's head, the U-Net
@@ -1263,13 +1274,17 @@ static int fill_params_h(const sr_conv3x3_desc* d, ConvParamsH& p, const char* w
 #define SR_CHAIN_EPOCHS 256
 extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return 0;
-  return 1 + SR_CHAIN_EPOCHS + (size_t)n * sr::cdiv(h, 16) * sr::cdiv(w, 32);
+  return 1 + SR_CHAIN_EPOCHS + (size_t)n * sr::cdiv(h, 8) * sr::cdiv(w, 32);  // (progress words: one per 8-row tile, the smallest)
 }
 
 // Default: 16-row tiles, two workgroups per CU (mode 2).  Same box, BASELINE config 2 in bf16 (batch 16, 20 steps): conv by conv
 // 1502 img/s, mode 2 1541, mode 1 (32-row ring tiles, one workgroup per CU) 1458; a dense block alone 159 -> 147 us at batch 16,
 // 310 -> 272 us at batch 32, 771 -> 664 us on four 544x544 tiler cells.  With two workgroups per CU one's hand-off, prologue and
 // epilogue overlap the other's MFMA loop; the single 32-row workgroup has nothing to overlap them with.
+// Off: measured on the reference recipe (batch 32 of 32x32 patches: 64 tiles of 16 rows or 128 of 8 on 256 CUs) the step is 22.17 / 22.18 ms on
+// 8-row tiles against 21.38 / 21.57 on 16-row tiles, same box — a tile's time is its ~43 steps of barrier and hand-off, not its MFMAs,
+// so halving the rows halves nothing.  The instance stays for tuning (sr_dev_set_fused_rows8) and is bit-exact (tests/test_chain_bf16_gpu.py).
+static int g_fused_rows8 = 0;
 static int g_chain_enabled = 3;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
                                  // 3 = fused dense block (rdb_fused_bf16_kernel) where eligible, else as 2
 static long long* g_chain_clocks = nullptr;
@@ -1330,7 +1345,18 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   if (cu_count[dev] < 1) return SR_OK;
   const int conc = sr::launch_concurrency();
   const int avail = cu_count[dev] / (conc > 1 ? conc : 1);
-  const int tiles_x = sr::cdiv(w, 32), tiles_y = h / 16;
+  // 8-row tiles where 16-row tiles would give fewer than half of the CUs a tile (a tile's five convs are one dependency chain)
+  const bool rows8 = g_fused_rows8 && (long long)sr::cdiv(w, 32) * (h / 16) * n * 2 <= avail;
+  if (rows8) {
+    static bool lds8[16] = {false};
+    if (!lds8[dev]) {
+      if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused8_bf16_kernel<0>, fz8::LDS_BYTES)) return rc;
+      if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused8_bf16_kernel<1>, fz8::LDS_BYTES)) return rc;
+      if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused8_bf16_kernel<2>, fz8::LDS_BYTES)) return rc;
+      lds8[dev] = true;
+    }
+  }
+  const int tiles_x = sr::cdiv(w, 32), tiles_y = h / (rows8 ? 8 : 16);
   const int T = tiles_x * tiles_y;
   // the tiles in flight are a window of the row-major tile order (see the kernel): it must hold the rows a block's hand-offs can block
   const long long NT = (long long)T * n;
@@ -1407,7 +1433,17 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     r.bytes = 2.0 * px * (64 + 128 + 64 + (d[4].res1 ? 64 : 0) + (d[4].res2 ? 64 : 0) + (d[0].mask_src ? 128 : 0));
     sr::prof_begin(stream, r);
   }
-  if (lean)
+  if (rows8) {
+    static_assert(sizeof(fz8::FusedParams) == sizeof(fz::FusedParams), "one parameter block for both tile heights");
+    fz8::FusedParams P8;
+    std::memcpy(&P8, &P, sizeof(P));
+    if (lean)
+      hipLaunchKernelGGL(rdb_fused8_bf16_kernel<1>, dim3((unsigned)grid), dim3(512), fz8::LDS_BYTES, stream, P8);
+    else if (back)
+      hipLaunchKernelGGL(rdb_fused8_bf16_kernel<2>, dim3((unsigned)grid), dim3(512), fz8::LDS_BYTES, stream, P8);
+    else
+      hipLaunchKernelGGL(rdb_fused8_bf16_kernel<0>, dim3((unsigned)grid), dim3(512), fz8::LDS_BYTES, stream, P8);
+  } else if (lean)
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
   else if (back)
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<2>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
@@ -1418,6 +1454,8 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   *launched = true;
   return SR_OK;
 }
+
+extern "C" void sr_dev_set_fused_rows8(int on) { g_fused_rows8 = on; }
 
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -10,14 +10,17 @@
 #endif
 namespace SR_FZ_NS {
 constexpr int NW = 8, PT = SR_FZ_PT, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
-constexpr int XU = 20, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer (18 x 34 pixels x 32 B, rounded up)
+constexpr int XU = (XPIX * 32 + 1023) / 1024, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer ((TH + 2) x 34 pixels x 32 B, rounded up: 20 / 11)
+constexpr int TPW = (2 * XU + NW - 1) / NW;  // pieces of a tile pair (two chunks) per wave: 5 (exactly 40 pieces) / 3 (22 pieces + 2 into a spare KB)
+constexpr bool kTileSurplus = TPW * NW > 2 * XU;
 constexpr int RING = 36;                            // weight ring, pieces
 constexpr int LDS_W0 = 0;                           // the ring first: its reads then need no address arithmetic (16-bit offsets)
 constexpr int LDS_X0 = RING * 1024;                 // tile buffers
 constexpr int LDS_FLAGS = LDS_X0 + NTB * XBUF;      // 64 words: neighbour progress words land here
 constexpr int LDS_BIAS = LDS_FLAGS + 256;           // 5 x 64 floats
 constexpr int LDS_WTAB = LDS_BIAS + 5 * 64 * 4;     // source offset of every weight piece (480 words)
-constexpr int LDS_BYTES = LDS_WTAB + 480 * 4;
+constexpr int LDS_SPARE = LDS_WTAB + 480 * 4;       // 1 KB for the surplus pieces of a tile pair (8-row tiles only)
+constexpr int LDS_BYTES = LDS_SPARE + (kTileSurplus ? 1024 : 0);
 static_assert(LDS_BYTES <= 160 * 1024, "fused dense block: LDS");
 constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
 constexpr int MAXSTEPS = 80, MAXP = 480;
@@ -204,9 +207,9 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
   // the issue sequence of one wave: what is younger than the operations a step needs may stay in flight at its wait
   int cseq = 0;
   int seq = 0, gend[MAXP / 8] = {}, tend[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, send[5] = {0, 0, 0, 0, 0}, fseq[5] = {0, 0, 0, 0, 0};
-  seq += 5;  // chunks 0-1 of x: 40 pieces = 5 per wave
+  seq += TPW;  // chunks 0-1 of x: 2 XU pieces = TPW per wave
   tend[0][0] = seq;
-  seq += 5;  // chunks 2-3
+  seq += TPW;  // chunks 2-3
   tend[0][1] = seq;
   int issued = RING / 8;  // whole groups that fit the empty ring
   s.q_init = issued;
@@ -232,7 +235,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     if (d.claim == 2) d.Kclaim = seq - cseq;  // (handed over before this step issues anything)
     if (d.tile_in) {
       d.Kflag = seq - fseq[d.tile_in];
-      seq += 5;  // two chunks: 40 pieces
+      seq += TPW;  // two chunks
       tend[d.tile_in][0] = seq;
     }
     int q1 = (d.wp0 + RING) / 8;
@@ -241,14 +244,14 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     d.q1 = q1;
     for (int q = issued; q < q1; ++q) gend[q] = ++seq;
     issued = q1;
-    if (d.nx_tile) seq += 5;
+    if (d.nx_tile) seq += TPW;
     seq += d.nx_q1 - d.nx_q0;
-    if (mode && d.first_of_in == 4) seq += 16;  // lean kernels: conv5's residual sources are fetched here
-    if (mode == 2 && mask_conv_at(s, i)) seq += 4;  // ... and conv k's mask kMaskLead steps before its epilogue
+    if (mode && d.first_of_in == 4) seq += 8 * PT;  // lean kernels: conv5's residual sources are fetched here (2 sources x 2 cout tiles x PT rows x 2 blocks)
+    if (mode == 2 && mask_conv_at(s, i)) seq += 2 * PT;  // ... and conv k's mask kMaskLead steps before its epilogue
     if (d.claim == 1) cseq = seq;  // thread 0 only: the ticket atomic, behind everything this step issues
     if (d.flag_in) fseq[d.flag_in] = seq;  // wave 0 only: one more instruction right here (not counted: the other waves' waits get stricter)
     if (d.post >= 1 && d.post <= 4) {
-      seq += 4;  // the epilogue's stores: 2 rows x 2 channel blocks
+      seq += 2 * PT;  // the epilogue's stores: PT rows x 2 channel blocks
       send[d.post] = seq;
     }
     if (d.K > 60 || d.Kflag > 60 || d.Kclaim > 60) s.ok = 0;

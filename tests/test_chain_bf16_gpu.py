@@ -65,6 +65,8 @@ def _fresh(dev, n, nf, gc, h, w, seed):
     (5, 208, 96, 64, 32),      # fused kernel: 39 tiles per image, a window of 195 tiles
     (2, 544, 544, 64, 32),     # fused kernel: a tiler cell = 578 tiles per image, more than CUs: the window slides down the image
     (3, 320, 1088, 64, 32),    # fused kernel: 34 tiles per row, 680 per image
+    (32, 32, 32, 64, 32),      # the recipe's batch of 32x32 patches: 64 tiles
+    (6, 48, 72, 64, 32),       # ragged width, 3 tile rows per image
 ])
 @pytest.mark.parametrize('mode', [1, 2, 3])
 def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
@@ -84,6 +86,34 @@ def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
         assert torch.equal(cat_a.buf, cat_b.buf), rep
         assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
     assert bool(torch.isfinite(nxt_b.buf[:, :nf // 16].float()).all())
+
+
+@pytest.mark.parametrize('n,h,w', [(32, 32, 32), (6, 48, 72), (2, 64, 40)])
+def test_fused_block_on_8_row_tiles_equals_conv_by_conv_bit_for_bit(cuda, n, h, w):
+    """The fused kernel's second instance (one row per wave: 8-row tiles, `sr_dev_set_fused_rows8`; off by default, it measured
+    slower on the launches it is meant for) against conv-by-conv launches, forward block."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.sr_dev_set_fused_rows8.argtypes = [C.c_int]
+    lib.sr_dev_set_fused_rows8.restype = None
+    nf, gc = 64, 32
+    _lib.check(lib.sr_set_conv_chain(3), 'sr_set_conv_chain')
+    packs = _rdb(cuda, nf, gc, 3)
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
+    for src, pc, out, kw in _steps(cat_a, nxt_a, packs, nf, gc):
+        H.conv3x3_bf16(src, pc, out, **kw)
+    lib.sr_dev_set_fused_rows8(1)
+    try:
+        sync = None
+        for rep in range(3):
+            cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+            _, sync = H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc), sync, call_index=rep)
+            torch.cuda.synchronize()
+            assert int(sync[0]) == 0, 'a dependency wait timed out'
+            assert torch.equal(cat_a.buf, cat_b.buf), rep
+            assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
+    finally:
+        lib.sr_dev_set_fused_rows8(0)
 
 
 @pytest.mark.parametrize('mode', [1, 2, 3])
@@ -135,7 +165,7 @@ def test_chain_can_be_switched_off(cuda):
     assert torch.equal(cat_a.buf, cat_b.buf) and torch.equal(nxt_a.buf[:, :4], nxt_b.buf[:, :4])
 
 
-@pytest.mark.parametrize('n,h,w', [(16, 128, 128), (20, 128, 128), (5, 208, 96), (2, 64, 40)])
+@pytest.mark.parametrize('n,h,w', [(16, 128, 128), (20, 128, 128), (5, 208, 96), (2, 64, 40), (32, 32, 32), (6, 48, 72)])
 @pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('closing', [False, True])
 def test_transposed_block_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, mode, closing):

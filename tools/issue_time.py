@@ -22,6 +22,11 @@ if len(sys.argv) > 6:
 if os.environ.get('CHAIN_F32'):   # development: the fp32 dense block as one persistent launch (off by default)
     from image_restoration_amd import _lib
     _lib.check(_lib.load().sr_set_conv_chain_f32(int(os.environ['CHAIN_F32'])), 'sr_set_conv_chain_f32')
+if os.environ.get('ROWS8'):   # development: 0 = the fused dense block on 16-row tiles only
+    import ctypes as _C
+    from image_restoration_amd import _lib as _l
+    _l.load().sr_dev_set_fused_rows8.argtypes = [_C.c_int]
+    _l.load().sr_dev_set_fused_rows8(int(os.environ['ROWS8']))
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ))).cuda()
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ))).cuda()
