@@ -838,9 +838,23 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 #undef SR_FZ_KERNEL
 // ... and on 8-row tiles (one row per wave), for launches whose 16-row tiles would leave most of the chip idle: a batch of 32 x 32
 // training patches is 64 tiles of 16 x 32 on 256 CUs, and a tile's five convs are one dependency chain
+// (their tile buffers are 11 KB instead of 20: the weight ring grows to 64 pieces, which lets the partial-sum phases advance a whole
+// chunk per step — 34 steps per tile instead of 62 — with hand-off lags of one or two of those longer steps)
 #define SR_FZ_NS fz8
 #define SR_FZ_PT 1
 #define SR_FZ_KERNEL rdb_fused8_bf16_kernel
+#undef SR_FZ_RING
+#undef SR_FZ_PERDX
+#undef SR_FZ_CLAIMLEAD
+#undef SR_FZ_PUBLAG
+#undef SR_FZ_TILELAG
+#undef SR_FZ_FLAGLEAD
+#define SR_FZ_RING 64
+#define SR_FZ_PERDX 0
+#define SR_FZ_CLAIMLEAD 2
+#define SR_FZ_PUBLAG {1, 1, 1, 1}
+#define SR_FZ_TILELAG {2, 2, 2, 2}
+#define SR_FZ_FLAGLEAD {1, 1, 1, 1}
 #include "fused_block.inc"
 #undef SR_FZ_NS
 #undef SR_FZ_PT
@@ -1281,10 +1295,11 @@ extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
 // 1502 img/s, mode 2 1541, mode 1 (32-row ring tiles, one workgroup per CU) 1458; a dense block alone 159 -> 147 us at batch 16,
 // 310 -> 272 us at batch 32, 771 -> 664 us on four 544x544 tiler cells.  With two workgroups per CU one's hand-off, prologue and
 // epilogue overlap the other's MFMA loop; the single 32-row workgroup has nothing to overlap them with.
-// Off: measured on the reference recipe (batch 32 of 32x32 patches: 64 tiles of 16 rows or 128 of 8 on 256 CUs) the step is 22.17 / 22.18 ms on
-// 8-row tiles against 21.38 / 21.57 on 16-row tiles, same box — a tile's time is its ~43 steps of barrier and hand-off, not its MFMAs,
-// so halving the rows halves nothing.  The instance stays for tuning (sr_dev_set_fused_rows8) and is bit-exact (tests/test_chain_bf16_gpu.py).
-static int g_fused_rows8 = 0;
+// 8-row tiles with a whole chunk per step (34 steps per tile instead of 62) where 16-row tiles would give fewer than half of the CUs a
+// tile.  1 (default): forward blocks only.  A block alone: 42.7 -> 31.6 us at 32 x 32x32, 41.7 -> 31.5 us on one 64x64 image; the
+// reference recipe's step 21.2 -> 20.0 ms.  2 = also the transposed block of the backward pass: 21.9 ms — that block shares the chip
+// with the weight-gradient lane, which loses more CUs to 128 small tiles than the block gains.  (sr_dev_set_fused_rows8)
+static int g_fused_rows8 = 1;
 static int g_chain_enabled = 3;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
                                  // 3 = fused dense block (rdb_fused_bf16_kernel) where eligible, else as 2
 static long long* g_chain_clocks = nullptr;
@@ -1346,7 +1361,10 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   const int conc = sr::launch_concurrency();
   const int avail = cu_count[dev] / (conc > 1 ? conc : 1);
   // 8-row tiles where 16-row tiles would give fewer than half of the CUs a tile (a tile's five convs are one dependency chain)
-  const bool rows8 = g_fused_rows8 && (long long)sr::cdiv(w, 32) * (h / 16) * n * 2 <= avail;
+  // (g_fused_rows8: 1 = forward blocks only — the transposed block of a backward pass shares the chip with the weight-gradient lane,
+  // which loses more CUs to 128 small tiles than the block gains; 2 = both)
+  const bool transposed_sig = !d[4].bpacked && d[0].mask_src != nullptr;
+  const bool rows8 = g_fused_rows8 && (g_fused_rows8 > 1 || !transposed_sig) && (long long)sr::cdiv(w, 32) * (h / 16) * n * 2 <= avail;
   if (rows8) {
     static bool lds8[16] = {false};
     if (!lds8[dev]) {

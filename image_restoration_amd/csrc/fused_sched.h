@@ -13,7 +13,10 @@ constexpr int NW = 8, PT = SR_FZ_PT, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * 
 constexpr int XU = (XPIX * 32 + 1023) / 1024, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer ((TH + 2) x 34 pixels x 32 B, rounded up: 20 / 11)
 constexpr int TPW = (2 * XU + NW - 1) / NW;  // pieces of a tile pair (two chunks) per wave: 5 (exactly 40 pieces) / 3 (22 pieces + 2 into a spare KB)
 constexpr bool kTileSurplus = TPW * NW > 2 * XU;
-constexpr int RING = 36;                            // weight ring, pieces
+#ifndef SR_FZ_RING
+#define SR_FZ_RING 36
+#endif
+constexpr int RING = SR_FZ_RING;                    // weight ring, pieces (36 beside six 20 KB tile buffers; the 8-row instance has room for more)
 constexpr int LDS_W0 = 0;                           // the ring first: its reads then need no address arithmetic (16-bit offsets)
 constexpr int LDS_X0 = RING * 1024;                 // tile buffers
 constexpr int LDS_FLAGS = LDS_X0 + NTB * XBUF;      // 64 words: neighbour progress words land here
@@ -59,15 +62,19 @@ struct Sched {
 // phases in execution order: {input group, first chunk, end chunk, first accumulator group, groups, one step per tap column (else per
 // chunk), conv completed}.  After conv k's own phase come partial sums that do not depend on x_k, ~144 MFMAs per wave and hand-off.
 constexpr int kNPhase = 13;
-constexpr int kPhase[kNPhase][7] = {{0, 0, 4, 0, 1, 0, 1},                                              // conv1 x
-                                    {0, 0, 4, 1, 2, 1, 0}, {0, 0, 2, 3, 3, 1, 0},                       //   conv2-3 x | conv4-5 x[0,1]
-                                    {1, 0, 2, 1, 1, 0, 2},                                              // conv2 x1
-                                    {0, 2, 4, 3, 3, 1, 0}, {1, 0, 2, 2, 1, 0, 0},                       //   conv4-5 x[2,3] | conv3 x1
-                                    {2, 0, 2, 2, 1, 0, 3},                                              // conv3 x2
-                                    {1, 0, 2, 3, 3, 1, 0}, {2, 0, 2, 3, 1, 0, 0},                       //   conv4-5 x1 | conv4 x2
-                                    {3, 0, 2, 3, 1, 0, 4},                                              // conv4 x3
-                                    {2, 0, 2, 4, 2, 1, 0}, {3, 0, 2, 4, 2, 1, 0},                       //   conv5 x2 | conv5 x3
-                                    {4, 0, 2, 4, 2, 1, 5}};                                             // conv5 x4
+#ifndef SR_FZ_PERDX
+#define SR_FZ_PERDX 1  // 1: the partial-sum phases advance one tap column per step (62 steps per tile); 0: one chunk per step (34; conv5's last input stays per column: the next tile's read-ahead needs those steps)
+#define SR_FZ_CLAIMLEAD 3  // steps between the ticket atomic and its hand-over
+#endif
+constexpr int kPhase[kNPhase][7] = {{0, 0, 4, 0, 1, 0, 1},                                                          // conv1 x
+                                    {0, 0, 4, 1, 2, SR_FZ_PERDX, 0}, {0, 0, 2, 3, 3, SR_FZ_PERDX, 0},               //   conv2-3 x | conv4-5 x[0,1]
+                                    {1, 0, 2, 1, 1, 0, 2},                                                          // conv2 x1
+                                    {0, 2, 4, 3, 3, SR_FZ_PERDX, 0}, {1, 0, 2, 2, 1, 0, 0},                         //   conv4-5 x[2,3] | conv3 x1
+                                    {2, 0, 2, 2, 1, 0, 3},                                                          // conv3 x2
+                                    {1, 0, 2, 3, 3, SR_FZ_PERDX, 0}, {2, 0, 2, 3, 1, 0, 0},                         //   conv4-5 x1 | conv4 x2
+                                    {3, 0, 2, 3, 1, 0, 4},                                                          // conv4 x3
+                                    {2, 0, 2, 4, 2, SR_FZ_PERDX, 0}, {3, 0, 2, 4, 2, SR_FZ_PERDX, 0},               //   conv5 x2 | conv5 x3
+                                    {4, 0, 2, 4, 2, 1, 5}};                                               // conv5 x4
 #ifndef SR_FZ_PUBLAG
 #define SR_FZ_PUBLAG {4, 2, 2, 3}
 #define SR_FZ_TILELAG {5, 4, 4, 5}
@@ -175,8 +182,8 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
       if (s.st[j].tile_in == 4) claim_at = j;
       if (s.st[j].first_of_in == 4) hand_at = j;
     }
-    if (claim_at < 0 || hand_at - 3 < claim_at || hand_at + 2 >= ns) s.ok = 0;
-    claim_at = hand_at - 3;  // (not earlier than necessary: the ticket waits in a register of thread 0 until the hand-over)
+    if (claim_at < 0 || hand_at - SR_FZ_CLAIMLEAD < claim_at || hand_at + 2 >= ns) s.ok = 0;
+    claim_at = hand_at - SR_FZ_CLAIMLEAD;  // (not earlier than necessary: the ticket waits in a register of thread 0 until the hand-over)
     s.st[claim_at].claim = 1;
     s.st[hand_at].claim = 2;
     const int n1 = last01 + 1 > hand_at + 1 ? last01 + 1 : hand_at + 1;
@@ -260,7 +267,9 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
   return s;
 }
 constexpr Sched kS = make_sched(0), kSL = make_sched(1), kSB = make_sched(2);
+#ifndef SR_FZ_PROBE
 static_assert(kS.ok == 1 && kSL.ok == 1 && kSB.ok == 1 && kS.nsteps <= MAXSTEPS && kS.npieces == 468, "fused dense block schedule");
+#endif
 template <int MODE, int S>
 constexpr int step_K() { return MODE == 0 ? kS.st[S].K : MODE == 1 ? kSL.st[S].K : kSB.st[S].K; }
 template <int MODE, int S>

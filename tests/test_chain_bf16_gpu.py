@@ -90,8 +90,8 @@ def test_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, nf, gc, mode):
 
 @pytest.mark.parametrize('n,h,w', [(32, 32, 32), (6, 48, 72), (2, 64, 40)])
 def test_fused_block_on_8_row_tiles_equals_conv_by_conv_bit_for_bit(cuda, n, h, w):
-    """The fused kernel's second instance (one row per wave: 8-row tiles, `sr_dev_set_fused_rows8`; off by default, it measured
-    slower on the launches it is meant for) against conv-by-conv launches, forward block."""
+    """The fused kernel's second instance (one row per wave: 8-row tiles, a chunk per step; `sr_dev_set_fused_rows8`: 1 = forward
+    blocks of small launches, the default; 2 = transposed blocks too) against conv-by-conv launches, forward block."""
     import ctypes as C
     lib = _lib.load()
     lib.sr_dev_set_fused_rows8.argtypes = [C.c_int]
@@ -113,7 +113,7 @@ def test_fused_block_on_8_row_tiles_equals_conv_by_conv_bit_for_bit(cuda, n, h, 
             assert torch.equal(cat_a.buf, cat_b.buf), rep
             assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
     finally:
-        lib.sr_dev_set_fused_rows8(0)
+        lib.sr_dev_set_fused_rows8(1)
 
 
 @pytest.mark.parametrize('mode', [1, 2, 3])
@@ -172,7 +172,13 @@ def test_transposed_block_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, m
     """The data-gradient side of a dense block (sr_rrdbnet_backward_bf16): the same chain shape over D = [dY5 | dY4 .. dY1], no bias, the
     LeakyReLU-backward mask of the forward activation on conv1-4, the residual sum(s) on conv5 — in mode 3 the fused kernel's lean
     transposed-block epilogues (masks and residual sources fetched ahead of the epilogues)."""
-    _lib.check(_lib.load().sr_set_conv_chain(mode), 'sr_set_conv_chain')
+    import ctypes as C
+    lib = _lib.load()
+    lib.sr_dev_set_fused_rows8.argtypes = [C.c_int]
+    lib.sr_dev_set_fused_rows8.restype = None
+    _lib.check(lib.sr_set_conv_chain(mode), 'sr_set_conv_chain')
+    # small launches in mode 3: the transposed block also on the 8-row instance (switch 2; the default, 1, keeps it on 16-row tiles)
+    lib.sr_dev_set_fused_rows8(2 if (mode == 3 and n * h * w <= 32 * 32 * 32) else 1)
     nf, gc = 64, 32
     g = torch.Generator().manual_seed(7)
     packs = []
@@ -205,6 +211,7 @@ def test_transposed_block_chain_equals_conv_by_conv_bit_for_bit(cuda, n, h, w, m
         assert int(sync[0]) == 0
         assert torch.equal(cat_a.buf, cat_b.buf), rep
         assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
+    lib.sr_dev_set_fused_rows8(1)
 
 
 def test_handoff_watchdog_reports_a_raised_abort_word_once(cuda):

@@ -292,7 +292,8 @@ def test_bench_line_contract(cuda):
     assert cb['kind'] in ('port', 'reference') and cb['cores'] >= 1 and cb['value'] >= cb['median'] > 0 and cb['unit'] == 'images/sec'
     assert cb['sample'] and sum(len(v) for v in cb['all_rates'].values()) >= 3
     sec = d['secondary']
-    assert set(sec) == {'c2_infer_bf16', 'c3_train_step', 'c5_tiled_4k_bf16', 'c5_tiled_4k_fp32'} and not any('error' in v for v in sec.values()), sec
+    assert set(sec) == {'c2_infer_bf16', 'c3_train_step', 'c5_tiled_4k_bf16', 'c5_tiled_4k_fp32', 'recipe_train_step_bf16',
+                        'recipe_train_step_fp32'} and not any('error' in v for v in sec.values()), sec
     c2 = sec['c2_infer_bf16']
     assert c2['unit'] == 'images/sec' and c2['dtype'] == 'bf16' and c2['value'] > 500 and 'rdb_fused' in c2['roofline']['kernel']
     check_roofline(c2['roofline'])
