@@ -1364,7 +1364,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
   // (g_fused_rows8: 1 = forward blocks only — the transposed block of a backward pass shares the chip with the weight-gradient lane,
   // which loses more CUs to 128 small tiles than the block gains; 2 = both)
   const bool transposed_sig = !d[4].bpacked && d[0].mask_src != nullptr;
-  const bool rows8 = g_fused_rows8 && (g_fused_rows8 > 1 || !transposed_sig) && (long long)sr::cdiv(w, 32) * (h / 16) * n * 2 <= avail;
+  const bool rows8 = g_fused_rows8 >= 3 || (g_fused_rows8 && (g_fused_rows8 > 1 || !transposed_sig) && (long long)sr::cdiv(w, 32) * (h / 16) * n * 2 <= avail);  // (3: every launch, development)
   if (rows8) {
     static bool lds8[16] = {false};
     if (!lds8[dev]) {
