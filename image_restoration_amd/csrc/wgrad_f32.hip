@@ -540,7 +540,7 @@ namespace sr {
 int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
   const int e4 = r.P * r.ntap * 256;
   const int groups = r.groups > 0 ? r.groups : 1, gi = r.gi > 0 ? r.gi : 1;
-  int sch = (int)((r.splits + 63) / 64);
+  int sch = (int)((r.splits + 63) / 64);  // (finer chunks measured slower here: 72 -> 76 ms on the fp32 recipe step)
   // part holds 64 * 4*9*1024 floats and bpart 64*64: shrink the stage-1 fan-out of multi-group launches to fit
   int cap = (int)((size_t)64 * 4 * 9 * 1024 / ((size_t)groups * r.P * r.ntap * 1024));
   const int bcap = 4096 / ((groups / gi) * r.CT * 32);
@@ -581,7 +581,7 @@ int wgrad_reduce_rows(const WgradReduce* r, int nrows, hipStream_t stream) {
     max_e4 = std::max(max_e4, r[i].P * r[i].ntap * 256);
     max_e = std::max(max_e, r[i].P * r[i].ntap * 1024);
   }
-  int sch = (int)((r[0].splits + 63) / 64);
+  int sch = (int)((r[0].splits + 15) / 16);  // (16 splits per stage-1 block: the dense block's 64-split launches were ONE chunk of eight dependent rounds of loads)
   int cap = (int)((size_t)64 * 4 * 9 / (size_t)sum_p);  // part holds 64 * 4*9*1024 floats, bpart 64*64
   cap = std::min(cap, 4096 / (nrows * 32));
   if (cap < 1) {
