@@ -98,8 +98,19 @@ class RRDBNet(nn.Module):
         return _lib.RRDBNetCfg(self.num_in_ch, self.num_out_ch, s, self.num_feat, self.num_block, self.num_grow_ch)
 
     def _param_list(self):
-        """Parameters in state_dict order (what sr_rrdbnet_pack_f32 expects)."""
-        return [p for _, p in self.named_parameters()]
+        """Parameters in state_dict order (what sr_rrdbnet_pack_f32 expects).  The walk over the module tree (702 parameters, twice
+        per training step: 2.6 ms of host time) is cached; the cache is dropped when the first or the last parameter object is no
+        longer the module's (``load_state_dict(assign=True)``, a re-registered parameter) and by ``_apply`` (``.to()``, ``.cuda()``)."""
+        cached = self.__dict__.get('_plist')
+        if cached is not None and cached[0] is self.conv_first.weight and cached[-1] is self.conv_last.bias:
+            return cached
+        plist = [p for _, p in self.named_parameters()]
+        self.__dict__['_plist'] = plist
+        return plist
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop('_plist', None)
+        return super()._apply(fn, *args, **kwargs)
 
     def _ensure_packed(self, lib, cfg, stream):
         params = self._param_list()
@@ -165,7 +176,7 @@ class RRDBNet(nn.Module):
                                   'and input with .to("cuda")')
         if x.dim() != 4 or x.size(1) != self.num_in_ch:
             raise ValueError(f'expected [N, {self.num_in_ch}, H, W], got {tuple(x.shape)}')
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._param_list())):
             from .rrdbnet_autograd import rrdbnet_apply
             return rrdbnet_apply(self, x)
         return self._forward_inference(x)

@@ -56,6 +56,7 @@ class NetPack:
             elif log is not None:
                 log.warning(f'Params {name} will not be optimized.')
         self.adam = optim.FlatAdam(chosen, modules=[self.net], **settings)
+        self.adam.all_params = list(self.net.parameters())   # freeze() toggles these every step: one walk of the module tree, here
         return self.adam
 
     def attach_shadow(self, shadow_net):
@@ -64,7 +65,8 @@ class NetPack:
 
     # -------------------------------------------------------------- one optimiser step
     def freeze(self, frozen=True):
-        for p in self.net.parameters():
+        params = self.adam.all_params if self.adam is not None and getattr(self.adam, 'all_params', None) else list(self.net.parameters())
+        for p in params:
             p.requires_grad = not frozen
 
     def clear_grads(self):
