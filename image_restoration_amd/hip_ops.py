@@ -39,12 +39,17 @@ def cached_pack(kind, weight, bias, build):
         return build()
     sig = (weight.data_ptr(), weight._version, getattr(weight, '_sr_epoch', _pack_epoch)[0], _pack_epoch[0],
            None if bias is None else (bias.data_ptr(), bias._version))
-    key = (id(weight), kind)
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig:
-        return hit[2]
+    wid = id(weight)
+    slot = _pack_cache.get(wid)
+    if slot is None or slot[0]() is not weight:
+        # the entry (and the device memory of its images) goes when the parameter does
+        slot = (weakref.ref(weight, lambda _, wid=wid: _pack_cache.pop(wid, None)), {})
+        _pack_cache[wid] = slot
+    hit = slot[1].get(kind)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
     val = build()
-    _pack_cache[key] = (weakref.ref(weight), sig, val)
+    slot[1][kind] = (sig, val)
     return val
 
 
