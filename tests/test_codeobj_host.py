@@ -56,7 +56,7 @@ def _kernels(code_objects, needle):
     return {n: (path, md) for path, ks in code_objects for n, md in ks.items() if needle in n}
 
 
-@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4), ('wgrad_bf16_kernel', 10),
+@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('rdb_fused8_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4), ('wgrad_bf16_kernel', 10),
                                              ('wgrad_rdb_bf16_kernel', 2)])
 def test_one_workgroup_per_cu_kernels_have_no_scratch_and_no_spills(code_objects, needle, at_least):
     ks = _kernels(code_objects, needle)
@@ -76,8 +76,9 @@ def _regs(operands):
     return regs
 
 
-def test_fused_kernel_ticket_register_is_untouched_until_its_counted_wait(code_objects):
-    ks = _kernels(code_objects, 'rdb_fused_bf16_kernel')
+@pytest.mark.parametrize('needle', ['rdb_fused_bf16_kernel', 'rdb_fused8_bf16_kernel'])   # the 16-row and the 8-row instance
+def test_fused_kernel_ticket_register_is_untouched_until_its_counted_wait(code_objects, needle):
+    ks = _kernels(code_objects, needle)
     assert len(ks) == 3
     path = next(iter(ks.values()))[0]
     dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', path], check=True, capture_output=True,
