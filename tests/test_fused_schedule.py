@@ -21,10 +21,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, '..', 'image_restoration_amd', 'csrc')
 
 
-@pytest.fixture(scope='module')
-def schedules(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp('sched') / 'print_fused_sched')
-    subprocess.run(['g++', '-std=c++17', '-O1', '-I', CSRC, os.path.join(HERE, 'helpers', 'print_fused_sched.cpp'), '-o', exe], check=True)
+# the two instances conv_bf16.hip builds: 16-row tiles (the header's defaults) and 8-row tiles with a chunk per step (the macros
+# conv_bf16.hip sets in front of its second inclusion of fused_block.inc)
+INSTANCES = {
+    'rows16': [],
+    'rows8': ['-DSR_FZ_PT=1', '-DSR_FZ_RING=64', '-DSR_FZ_PERDX=0', '-DSR_FZ_CLAIMLEAD=2', '-DSR_FZ_PUBLAG={1,1,1,1}', '-DSR_FZ_TILELAG={2,2,2,2}',
+              '-DSR_FZ_FLAGLEAD={1,1,1,1}'],
+}
+
+
+@pytest.fixture(scope='module', params=sorted(INSTANCES))
+def schedules(request, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp('sched') / ('print_fused_sched_' + request.param))
+    subprocess.run(['g++', '-std=c++17', '-O1', '-fconstexpr-ops-limit=2000000000', '-fconstexpr-loop-limit=100000000', '-I', CSRC]
+                   + INSTANCES[request.param] + [os.path.join(HERE, 'helpers', 'print_fused_sched.cpp'), '-o', exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     return [json.loads(line) for line in out.strip().splitlines()]
 
@@ -40,7 +50,7 @@ def replay(s, following):
     ops = []
 
     def issue(kind, payload, step):
-        for _ in range(5 if kind in ('tile', 'nxtile') else 1):   # two tile chunks = 40 pieces of 1 KB = five per wave
+        for _ in range(s['tpw'] if kind in ('tile', 'nxtile') else 1):   # two tile chunks = 2 XU pieces of 1 KB, TPW per wave (40 = five each on 16-row tiles)
             ops.append((kind, payload, step))
         return len(ops)          # position: number of ops issued up to and including this one
 
@@ -79,15 +89,15 @@ def replay(s, following):
         if d['flag_in']:
             pos[('flagfetch', d['flag_in'])] = len(ops)     # wave 0 only: its extra op sits here, the others' waits only get stricter
         if mode != 0 and d['first_of_in'] == 4:
-            for _ in range(16):
+            for _ in range(8 * s['pt']):   # 2 sources x 2 cout tiles x PT rows x 2 channel blocks
                 issue('res', None, i)
         if mode == 2 and d['mask_conv']:
-            for _ in range(4):
+            for _ in range(2 * s['pt']):
                 issue('mask', d['mask_conv'], i)
         if d['claim'] == 1:
             pos[('claim',)] = len(ops)                      # thread 0 only
         if 1 <= d['post'] <= 4:
-            for _ in range(4):
+            for _ in range(2 * s['pt']):   # PT rows x 2 channel blocks
                 pos[('st', d['post'])] = issue('store', d['post'], i)
     return ops, pos, waits
 
@@ -190,3 +200,15 @@ def test_accumulators_and_mfma_order(schedules):
         assert order[g] == expect, g
     posts = [d['post'] for d in s['steps'] if d['post']]
     assert posts == [1, 2, 3, 4, 5]
+
+
+def test_model_instances_are_the_ones_the_library_builds():
+    """INSTANCES['rows8'] above must be the macro set conv_bf16.hip puts in front of its second inclusion of fused_block.inc."""
+    import re
+    src = open(os.path.join(CSRC, 'conv_bf16.hip')).read()
+    block = src[src.index('#define SR_FZ_NS fz8'):]
+    block = block[:block.index('#include "fused_block.inc"')]
+    defs = dict(re.findall(r'#define (SR_FZ_\w+) (.+)', block))
+    want = {k: v.replace(' ', '') for k, v in defs.items() if k not in ('SR_FZ_NS', 'SR_FZ_KERNEL')}
+    have = dict(m.lstrip('-D').split('=', 1) for m in INSTANCES['rows8'])
+    assert want == have, (want, have)
