@@ -306,6 +306,45 @@ def test_bench_line_contract(cuda):
     check_roofline(sec['c5_tiled_4k_bf16']['roofline'])
 
 
+def test_bench_gpus_2_as_one_command(cuda):
+    """``python bench.py --gpus 2 ...`` typed as ONE command (no external launcher): the parent starts torch.distributed.run itself
+    before touching the GPU (reference entry: scripts/dist_train.sh:15-16, utils/dist_util.py:21-25).  Two gloo ranks share this
+    box's one GPU (SR_BENCH_BACKEND=gloo; on a multi-GPU node the default backend is RCCL): rc 0, one JSON line, n_gpus == 2, the
+    process group's own view of the ranks, all six secondaries, no dense-block launch fell back.  The line is kept under
+    gpurun_out/ for profiles/."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SR_BENCH_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--secondary-timeout', '900'], capture_output=True, text=True, timeout=1100, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert 'starting 2 ranks' in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'bench_gpus2_one_command.json'), 'w') as f:
+            f.write(lines[0] + '\n')
+    except OSError:
+        pass
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['config']['global_batch'] == 32
+    assert abs(d['value'] - 32 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 0.05 * d['value']
+    rv = d['ranks']
+    assert rv['world_size'] == 2 and rv['backend'] == 'gloo' and [p['rank'] for p in rv['per_rank']] == [0, 1]
+    assert rv['images_per_sec_min'] > 0 and rv['images_per_sec_max'] >= rv['images_per_sec_min']
+    sec = d['secondary']
+    assert set(sec) == {'c2_infer_bf16', 'c3_train_step', 'c5_tiled_4k_bf16', 'c5_tiled_4k_fp32', 'recipe_train_step_bf16',
+                        'recipe_train_step_fp32'} and not any('error' in v for v in sec.values()), sec
+    assert sec['c3_train_step']['config']['global_batch'] == 64 and sec['c3_train_step']['n_gpus'] == 2
+    for key in ('c5_tiled_4k_bf16', 'c5_tiled_4k_fp32'):
+        assert sec[key]['handoff_fallbacks'] == 0 and sec[key]['n_gpus'] == 2
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
 def test_tiled_forward_at_the_4k_cell_size_equals_the_untiled_forward_of_every_padded_cell(cuda, dtype):
     """BASELINE config 5's geometry (512 x 512 LR cells + 16 px pad, 23 blocks, nf 64) on a 1024 x 1024 frame: each assembled

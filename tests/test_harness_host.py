@@ -210,3 +210,19 @@ def test_option_parsing_matches_the_reference(golden):
             assert mine == ref, (rel, debug, {k: (mine.get(k), ref.get(k)) for k in set(mine) | set(ref) if mine.get(k) != ref.get(k)})
             if not debug:
                 assert dict2str(opt) == str(g[f'f{i}_str']), rel
+
+
+def test_bench_gpus_n_starts_its_own_ranks_without_touching_the_gpu():
+    """``python bench.py --gpus 2`` with no launcher in the environment starts torch.distributed.run as a child process (reference
+    entry: scripts/dist_train.sh:15-16) and returns its code.  Here there is no GPU, so both ranks stop at bench.py's "needs a GPU"
+    check: what is asserted is that the RANKS said so (the parent never asked for the device) and that the failure is ours."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-secondary'],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert 'starting 2 ranks' in r.stderr and '--nproc-per-node 2' in r.stderr and '--master-addr 127.0.0.1' in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and 'bench.py needs a GPU' in r.stderr
