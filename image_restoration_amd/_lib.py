@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SR_HIP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libsr_hip.so')  # override: A/B builds of the kernels
 
-SR_ABI_VERSION = 2
+SR_ABI_VERSION = 3
 
 
 class SrHipError(RuntimeError):
@@ -52,6 +52,11 @@ class RRDBNetCfg(C.Structure):
     """struct sr_rrdbnet_cfg (include/sr_hip.h)."""
     _fields_ = [('num_in_ch', C.c_int), ('num_out_ch', C.c_int), ('scale', C.c_int), ('num_feat', C.c_int),
                 ('num_block', C.c_int), ('num_grow_ch', C.c_int)]
+
+
+class VGGCfg(C.Structure):
+    """struct sr_vgg_cfg (include/sr_hip.h)."""
+    _fields_ = [('num_in_ch', C.c_int), ('num_feat', C.c_int), ('input_size', C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/sr_hip.h declares
@@ -231,6 +236,22 @@ SIGNATURES.update({
     'sr_profile_stop': (C.c_int, [C.POINTER(LaunchRecord), C.c_int, C.POINTER(C.c_int)]),
     'sr_kernel_name': (C.c_char_p, [C.c_int]),
 })
+
+for _suf, _plain in (('_f32', ''), ('_bf16', '_bf16')):
+    SIGNATURES.update({
+        'sr_vgg_packed_bytes' + _plain: (C.c_size_t, [C.POINTER(VGGCfg)]),
+        'sr_vgg_saved_bytes' + _plain: (C.c_size_t, [C.POINTER(VGGCfg), C.c_int]),
+        'sr_vgg_workspace_bytes' + _plain: (C.c_size_t, [C.POINTER(VGGCfg), C.c_int]),
+        'sr_vgg_pack' + _suf: (C.c_int, [C.POINTER(VGGCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+        'sr_vgg_forward' + _suf: (C.c_int, [C.POINTER(VGGCfg), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+        'sr_vgg_apply_stats' + _suf: (C.c_int, [C.POINTER(VGGCfg), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                                C.c_void_p]),
+        'sr_vgg_backward' + _suf: (C.c_int, [C.POINTER(VGGCfg), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p]),
+    })
+SIGNATURES.update({'sr_vgg_num_params': (C.c_int, [C.POINTER(VGGCfg)]), 'sr_vgg_num_batchnorm': (C.c_int, [C.POINTER(VGGCfg)])})
 
 _lib = None
 

@@ -3,9 +3,12 @@
 Same constructor, forward contract and state_dict keys as the reference
 ``basicsr/archs/discriminator_arch.py:6-72`` (conv{i}_{0,1}, bn{i}_{0,1} incl. running statistics and
 num_batches_tracked, linear1, linear2), so ``network_d: {type: VGGStyleDiscriminator128, ...}`` and saved
-``net_d_*.pth`` files drop in.  The modules hold parameters only; the arithmetic is HIP launches
-(hip_autograd.ConvFn / BNLReLUFn / LinearFn).
+``net_d_*.pth`` files drop in.  The modules hold parameters only; the arithmetic is HIP launches: by default one whole-network
+driver call per forward / backward (archs/vgg_disc_autograd.py -> sr_vgg_forward_* / sr_vgg_backward_*); the per-layer route
+(hip_autograd.ConvFn / BNLReLUFn / LinearFn, ``forward_layers``) issues the same launches one autograd function at a time
+and is kept as the cross-check of the drivers and for partially frozen networks.
 """
+import ctypes as C
 import math
 
 import torch
@@ -91,12 +94,105 @@ class VGGStyleDiscriminator128(nn.Module):
             setattr(self, f'bn{i}_1', BatchNormParams(co))
         self.linear1 = LinearParams(nf * 8 * 4 * 4, 100)
         self.linear2 = LinearParams(100, 1)
+        self._packed = {}          # dtype -> (key, device blob of forward + data-gradient weight images)
+        self._grad_sink = None     # set by optim.FlatAdam: gradients accumulate straight into its arena
+        self._ws = None
+        self._pack_epoch = 0
 
-    def forward(self, x):
+    # train-mode forwards are pure functions of (weights, input): models may run a repeated forward once (vgg_disc_autograd.py)
+    repeatable_forward = True
+
+    # ------------------------------------------------------------------ HIP plumbing (mirrors RRDBNet's)
+    def invalidate_packed(self):
+        """Parameter memory was rewritten behind autograd's back (fused Adam writes the arena through raw pointers)."""
+        self._pack_epoch += 1
+
+    def _cfg(self):
+        return _lib.VGGCfg(self.num_in_ch, self.num_feat, self.input_size)
+
+    def _param_list(self):
+        cached = self.__dict__.get('_plist')
+        if cached is not None and cached[0] is self.conv0_0.weight and cached[-1] is self.linear2.bias:
+            return cached
+        plist = [p for _, p in self.named_parameters()]
+        self.__dict__['_plist'] = plist
+        self.__dict__.pop('_bufptrs', None)
+        return plist
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop('_plist', None)
+        self.__dict__.pop('_bufptrs', None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def _buffer_ptrs(self):
+        """running_mean, running_var, num_batches_tracked of every BatchNorm in module order (sr_vgg_forward's host_buffers)."""
+        bufs = [b for _, b in self.named_buffers()]
+        key = tuple(b.data_ptr() for b in bufs)
+        cached = self.__dict__.get('_bufptrs')
+        if cached is None or cached[0] != key:
+            lib = _lib.load()
+            assert len(bufs) == 3 * lib.sr_vgg_num_batchnorm(C.byref(self._cfg())), len(bufs)
+            for i, b in enumerate(bufs):
+                assert b.dtype == (torch.int64 if i % 3 == 2 else torch.float32) and b.is_contiguous()
+            cached = (key, (C.c_void_p * len(bufs))(*key))
+            self.__dict__['_bufptrs'] = cached
+        return cached[1]
+
+    def _weights_key(self):
+        """Identity of the current weights: parameter storage + torch version counters + the epochs of writers torch cannot
+        see (FlatAdam's fused step, invalidate_packed, hip_ops.invalidate_packs)."""
+        from .. import hip_ops
+        params = self._param_list()
+        return (self._pack_epoch, hip_ops._pack_epoch[0], getattr(params[0], '_sr_epoch', (0,))[0],
+                tuple((p.data_ptr(), p._version) for p in params))
+
+    def _ensure_packed(self, lib, cfg, stream, bf16):
+        key = self._weights_key()
+        hit = self._packed.get(bf16)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        params = self._param_list()
+        n = lib.sr_vgg_num_params(C.byref(cfg))
+        if n != len(params):
+            raise _lib.SrHipError(f'parameter count {len(params)} != {n} expected by libsr_hip.so')
+        dev = params[0].device
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SrHipError('discriminator parameters must be contiguous fp32 on one HIP device')
+        nbytes = (lib.sr_vgg_packed_bytes_bf16 if bf16 else lib.sr_vgg_packed_bytes)(C.byref(cfg))
+        blob = hit[1] if hit is not None and hit[1].numel() == nbytes and hit[1].device == dev else \
+            torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in params])
+        _lib.check((lib.sr_vgg_pack_bf16 if bf16 else lib.sr_vgg_pack_f32)(C.byref(cfg), ptrs, blob.data_ptr(), stream), 'sr_vgg_pack')
+        self._packed[bf16] = (key, blob)
+        return blob
+
+    def _workspace(self, lib, cfg, n, dev, bf16):
+        nbytes = (lib.sr_vgg_workspace_bytes_bf16 if bf16 else lib.sr_vgg_workspace_bytes)(C.byref(cfg), n)
+        ws = self._ws
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws, nbytes
+
+    def _check_input(self, x):
         sz = self.input_size
         assert x.size(2) == sz and x.size(3) == sz, (f'Input spatial size must be {sz}x{sz}, but received {x.size()}.')
         if not x.is_cuda:
             raise _lib.SrHipError(f'{type(self).__name__}.forward runs only on a HIP device (no CPU fallback)')
+
+    def forward(self, x, kept=None, slot=None):
+        """``kept`` / ``slot``: see archs/vgg_disc_autograd.vgg_apply (a model that knows two calls see the same input and
+        weights hands the first call's KeptForward to the second)."""
+        self._check_input(x)
+        flags = {p.requires_grad for p in self._param_list()}
+        if len(flags) > 1 and torch.is_grad_enabled():
+            return self.forward_layers(x)   # partially frozen: the per-layer route handles any mixture
+        from .vgg_disc_autograd import vgg_apply
+        return vgg_apply(self, x, kept, slot)
+
+    def forward_layers(self, x):
+        """The same network one autograd function per layer (the route of rounds 1-3): same launches, same bits."""
+        self._check_input(x)
         if self.compute_dtype == 'bf16':
             return self._forward_bf16(x)
         feat = A.ToCB8.apply(x.contiguous().float())

@@ -12,6 +12,15 @@ A step has two phases:
 ``_critic_phase``     D live; real and fake are back-propagated by two separate backward calls that accumulate in the
                       gradient arena, which is exchanged ONCE before D's Adam (the reference's DDP exchanges twice;
                       sums are the same).
+
+Repeated discriminator forwards.  Within one step the reference calls ``net_d`` on the same two tensors several times while
+D's weights do not change (esrgan_model.py:38-39 in the generator phase, :65-66,70 in the critic phase: ``net_d(gt)`` twice,
+``net_d(output)`` three times; srgan_model.py:104,122: ``net_d(output)`` twice).  For a network whose train-mode forward is a
+pure function of (weights, input) — the BatchNorm VGG discriminators: batch statistics only, deterministic launches — the
+repeats are bit-identical, so ``_critic`` runs each distinct forward ONCE, keeps its activations for every backward that needs
+them, and replays only what a repeat changes: the BatchNorm running statistics and ``num_batches_tracked``, in the reference's
+call order.  This does NOT hold for UNetDiscriminatorSN: spectral normalisation does one power iteration per train-mode forward,
+which moves ``weight_u / weight_v`` and with them the effective weights, so its five forwards differ and all run.
 """
 import torch
 
@@ -38,6 +47,9 @@ class SRGANModel(SRModel):
         self._build_content_losses(cfg)
         if cfg.get('gan_opt'):
             self.cri_gan = build_loss(cfg['gan_opt']).to(self.device)
+        # option key beyond the reference's (default on): run a repeated forward of a repeatable discriminator once per step
+        self.reuse_d_forwards = bool(cfg.get('reuse_d_forwards', True))
+        self._d_kept, self.d_forwards_run = {}, 0
         self.net_d_iters = cfg.get('net_d_iters', 1)
         self.net_d_init_iters = cfg.get('net_d_init_iters', 0)
         self.setup_optimizers()
@@ -48,6 +60,22 @@ class SRGANModel(SRModel):
         self.optimizer_g = self.make_adam(self.gen, self.opt['train']['optim_g'])
         self.optimizer_d = self.make_adam(self.critic, self.opt['train']['optim_d'])
 
+    # ------------------------------------------------------------------ discriminator calls of one step
+    def _critic(self, x, tag):
+        """``self.net_d(x)``; ``tag`` names the tensor ('gt' / 'out').  With a repeatable network the first call of a tag in
+        this step runs and keeps the forward, later calls reuse it (module docstring).  The cache lives for one
+        optimize_parameters and is dropped before D's weights move."""
+        net = self.net_d
+        if not (getattr(net, 'repeatable_forward', False) and net.training and self.reuse_d_forwards):
+            self.d_forwards_run += 1
+            return net(x)
+        slot = []
+        out = net(x, kept=self._d_kept.get(tag), slot=slot)
+        if self._d_kept.get(tag) is not slot[0]:
+            self.d_forwards_run += 1
+        self._d_kept[tag] = slot[0]
+        return out
+
     def generator_turn(self, current_iter):
         """G trains every ``net_d_iters`` iterations once ``net_d_init_iters`` have passed."""
         return current_iter > self.net_d_init_iters and current_iter % self.net_d_iters == 0
@@ -56,22 +84,22 @@ class SRGANModel(SRModel):
     def _fool_critic(self):
         """Generator-side GAN term on ``self.output`` (graph into G)."""
         if not self.relativistic:
-            return self.cri_gan(self.net_d(self.output), True, is_disc=False)
+            return self.cri_gan(self._critic(self.output, 'out'), True, is_disc=False)
         with torch.no_grad():                      # esrgan_model.py:38 - real logits are constants for G
-            on_real = self.net_d(self.gt)
-        on_fake = self.net_d(self.output)
+            on_real = self._critic(self.gt, 'gt')
+        on_fake = self._critic(self.output, 'out')
         gan = self.cri_gan.relativistic
         return (gan(on_real, on_fake, False, is_disc=False) + gan(on_fake, on_real, True, is_disc=False)) / 2
 
     def _critic_phase(self, book):
         fake_img = self.output.detach()
         if not self.relativistic:
-            on_real = self.net_d(self.gt)
+            on_real = self._critic(self.gt, 'gt')
             loss_real = self.cri_gan(on_real, True, is_disc=True)
             book.log('l_d_real', loss_real)
             book.log('out_d_real', A.mean(on_real))
             loss_real.backward()
-            on_fake = self.net_d(fake_img)
+            on_fake = self._critic(fake_img, 'out')
             loss_fake = self.cri_gan(on_fake, False, is_disc=True)
             book.log('l_d_fake', loss_fake)
             book.log('out_d_fake', A.mean(on_fake))
@@ -79,11 +107,11 @@ class SRGANModel(SRModel):
             return
         gan = self.cri_gan.relativistic
         with torch.no_grad():   # the reference detaches this forward's result (:65); BatchNorm statistics still move
-            fake_const = self.net_d(fake_img)
-        on_real = self.net_d(self.gt)
+            fake_const = self._critic(fake_img, 'out')
+        on_real = self._critic(self.gt, 'gt')
         loss_real = gan(on_real, fake_const, True, is_disc=True) * 0.5
         loss_real.backward()
-        on_fake = self.net_d(fake_img)
+        on_fake = self._critic(fake_img, 'out')
         loss_fake = gan(on_fake, on_real.detach(), False, is_disc=True) * 0.5
         loss_fake.backward()
         book.log('l_d_real', loss_real)
@@ -106,10 +134,13 @@ class SRGANModel(SRModel):
     def optimize_parameters(self, current_iter):
         self.refresh_buffers()
         book = LossBook()
+        self._d_kept = {}
+        self.d_forwards_run = 0   # distinct discriminator forwards this step issued (5 calls per ESRGAN step)
         self._generator_phase(book, current_iter)
         self.critic.freeze(False)
         self.critic.clear_grads()
         self._critic_phase(book)
+        self._d_kept = {}         # D's weights move next: nothing kept survives them
         self.critic.update(self.distributed)
         self.finish_step(book)
 

@@ -40,7 +40,7 @@ extern "C" {
 #define SR_ELAUNCH (-2)  /* HIP launch/runtime error */
 #define SR_ENOSPACE (-3) /* workspace too small */
 
-#define SR_ABI_VERSION 2
+#define SR_ABI_VERSION 3
 
 /* ABI version of this library (SR_ABI_VERSION it was built with). */
 int sr_version(void);
@@ -508,6 +508,69 @@ int sr_rrdbnet_forward_train_bf16(const sr_rrdbnet_cfg* cfg, const void* packed,
 int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* packed_dgrad, const void* saved, size_t saved_bytes,
                              const float* dy, int n, int h, int w, float* const* host_dparams, float* dx, void* workspace,
                              size_t workspace_bytes, int accumulate, void* stream);
+
+/* -------------------------------------------------- whole VGG discriminator ---- */
+/* VGGStyleDiscriminator128 / VGGStyleDiscriminator256 (discriminator_arch.py:6-72, 75-143) as whole-network drivers
+ * shaped like the generator's above: one call issues every launch of a forward (:52-72) or of autograd's backward through
+ * it (esrgan_model.py:47,68,72) on `stream`; `saved` and `workspace` are caller-owned (sized by the *_bytes helpers), no
+ * allocation, no synchronisation, graph-capturable.  Each launch is the single-op entry point the per-layer host path
+ * uses, with the same descriptor, in the same order: results are bit-identical to that path.
+ *
+ * host_params: HOST array of sr_vgg_num_params() DEVICE pointers (fp32 masters) in state_dict order — conv0_0.{weight,bias},
+ *   conv0_1.weight, bn0_1.{weight,bias}, then per stage conv{i}_0.weight, bn{i}_0.{weight,bias}, conv{i}_1.weight,
+ *   bn{i}_1.{weight,bias}, then linear1.{weight,bias}, linear2.{weight,bias} (33 tensors for the 128 network).
+ * host_buffers: HOST array of 3 * sr_vgg_num_batchnorm() DEVICE pointers — running_mean, running_var (fp32) and
+ *   num_batches_tracked (int64, may be NULL) of each BatchNorm in module order.
+ * packed: forward and data-gradient weight images of the ten (twelve) convs, sr_vgg_pack_* — repack after every optimiser step.
+ *
+ * Train-mode BatchNorm does not read its running statistics, but every forward of the reference moves them
+ * (nn.BatchNorm2d, momentum 0.1, unbiased variance).  A train forward therefore leaves its update as delta vectors
+ * (momentum * batch statistic) in `saved` and applies them once:  running = (1 - momentum) * running + delta, the expression
+ * of the fused update, num_batches_tracked += 1.  sr_vgg_apply_stats_* applies the deltas of a kept `saved` block `repeats`
+ * more times: the ESRGAN step (esrgan_model.py:38-39,65-72) calls net_d(gt) twice and net_d(output) three times on unchanged
+ * weights, the repeats are bit-identical forwards, so a host runs each distinct forward once, keeps its `saved` block for
+ * every backward that needs it and replays the statistics of the repeats in the reference's order (host_buffers = NULL in
+ * sr_vgg_forward_* skips the update of that call, for a host that orders all of them itself).  Not valid for a
+ * spectral-norm network: one power iteration per forward changes the weights themselves.
+ *
+ * sr_vgg_forward_*:  x NCHW fp32 [n][num_in_ch][S][S] -> logits [n] (may be NULL: they also stay in `saved`);
+ *                    train = 0 uses (and does not move) the running statistics.
+ * sr_vgg_backward_*: dlogits [n] -> host_dparams (HOST array of DEVICE pointers shaped like the parameters; all NULL or
+ *                    host_dparams = NULL for a frozen discriminator; accumulate = 1 adds, which is how the two backward calls of
+ *                    the critic phase land in one gradient arena) and, if dx != NULL, dL/dx [n][num_in_ch][S][S].
+ *                    `train` = the flag the forward that filled `saved` ran with.
+ * The *_bf16 twins keep activations and their gradients as CB16 bf16; parameters, statistics, the linear head and every
+ * gradient that leaves the call stay fp32 (num_feat % 16 == 0). */
+typedef struct sr_vgg_cfg {
+  int num_in_ch, num_feat; /* VGGStyleDiscriminator128.__init__, discriminator_arch.py:18 */
+  int input_size;          /* 128 or 256 */
+} sr_vgg_cfg;
+int sr_vgg_num_params(const sr_vgg_cfg* cfg);
+int sr_vgg_num_batchnorm(const sr_vgg_cfg* cfg);
+size_t sr_vgg_packed_bytes(const sr_vgg_cfg* cfg);
+size_t sr_vgg_saved_bytes(const sr_vgg_cfg* cfg, int n);
+size_t sr_vgg_workspace_bytes(const sr_vgg_cfg* cfg, int n);
+int sr_vgg_pack_f32(const sr_vgg_cfg* cfg, const float* const* host_params, void* packed, void* stream);
+int sr_vgg_forward_f32(const sr_vgg_cfg* cfg, const void* packed, const float* const* host_params, void* const* host_buffers,
+                       const float* x, float* logits, int n, int train, void* saved, size_t saved_bytes, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int sr_vgg_apply_stats_f32(const sr_vgg_cfg* cfg, const void* saved, size_t saved_bytes, int n, void* const* host_buffers,
+                           int repeats, void* stream);
+int sr_vgg_backward_f32(const sr_vgg_cfg* cfg, const void* packed, const float* const* host_params, const void* saved,
+                        size_t saved_bytes, const float* dlogits, int n, int train, float* const* host_dparams, int accumulate,
+                        float* dx, void* workspace, size_t workspace_bytes, void* stream);
+size_t sr_vgg_packed_bytes_bf16(const sr_vgg_cfg* cfg);
+size_t sr_vgg_saved_bytes_bf16(const sr_vgg_cfg* cfg, int n);
+size_t sr_vgg_workspace_bytes_bf16(const sr_vgg_cfg* cfg, int n);
+int sr_vgg_pack_bf16(const sr_vgg_cfg* cfg, const float* const* host_params, void* packed, void* stream);
+int sr_vgg_forward_bf16(const sr_vgg_cfg* cfg, const void* packed, const float* const* host_params, void* const* host_buffers,
+                        const float* x, float* logits, int n, int train, void* saved, size_t saved_bytes, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int sr_vgg_apply_stats_bf16(const sr_vgg_cfg* cfg, const void* saved, size_t saved_bytes, int n, void* const* host_buffers,
+                            int repeats, void* stream);
+int sr_vgg_backward_bf16(const sr_vgg_cfg* cfg, const void* packed, const float* const* host_params, const void* saved,
+                         size_t saved_bytes, const float* dlogits, int n, int train, float* const* host_dparams, int accumulate,
+                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------ measurement ---- */
 
