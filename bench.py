@@ -238,6 +238,8 @@ def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dty
         raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
     else:
         opt['network_d']['compute_dtype'] = d_dtype
+    if os.environ.get('SR_BENCH_REUSE_D') == '0':   # tuning: every discriminator call of a step runs its own forward
+        opt['train']['reuse_d_forwards'] = False
     set_random_seed(opt['manual_seed'] + rank)   # like parse_options: ranks start different, the model aligns its replicas
     model = build_model(opt)
     x_lq = torch.from_numpy(synth.uniform_input(100 + rank, (batch, 3, lq, lq))).to(dev)
@@ -269,7 +271,8 @@ def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dty
         'config': {'workload': 'BASELINE configs[2-3]: ESRGANModel.optimize_parameters, batch %d of %dx%d LR patches per GPU'
                                % (batch, lq, lq), 'global_batch': world * batch,
                    'parallelism': 'dp%d, replicas aligned from rank 0 at construction, one all-reduce of each gradient arena per step' % world},
-        'losses': {k: float(v) for k, v in log.items()}}
+        'losses': {k: float(v) for k, v in log.items()},
+        'd_forwards_per_step': {'calls': 5 if type(model).__name__ == 'ESRGANModel' else 2, 'run': getattr(model, 'd_forwards_run', None)}}
     if profile and world == 1:
         peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
         ks = profile_launches(lambda: step(warmup + steps + 1), peak)

@@ -206,7 +206,7 @@ Space carve(const Plan& P, int n, char* base) {
     if (l.bn) small += 2 * sr::align_up((size_t)l.cout, 64);
     if (P.bf16 && l.k == 4) small += sr::align_up((size_t)l.cout * l.cin * 16, 64) + sr::align_up((size_t)l.cout * l.cin * 36, 64);
   }
-  small += sr::align_up((size_t)kHidden * P.nin1, 64) + sr::align_up((size_t)kHidden, 64) + 64 + 64;
+  small += sr::align_up((size_t)kHidden * P.nin1, 64) + 2 * sr::align_up((size_t)kHidden, 64) + 64;  // linear1.{weight,bias}, linear2.{weight,bias}
   W.A = take(big);
   W.B = take(big);
   W.Cb = P.bf16 ? take(big) : nullptr;
