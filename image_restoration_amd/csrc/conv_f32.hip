@@ -994,6 +994,7 @@ extern "C" const char* sr_kernel_name(int id) {
     return snames[id - 44];
   }
   if (id == 40) return "wgrad_rdb_bf16_kernel";
+  if (id == 48) return "wgrad_f32_rdb_kernel";
   if (id == 64) return "conv_stream_bf16_kernel";
   if (id == 60) return "rdb_fused_bf16_kernelILi0E";
   if (id == 61) return "rdb_fused_bf16_kernelILi1E";

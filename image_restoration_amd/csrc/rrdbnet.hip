@@ -18,6 +18,7 @@
 // writes all 192 channels of G (plus the residual branch on the first 64), conv4..conv1 accumulate
 // into the channels below their own slice, and the LeakyReLU backward of x_{k-1} is applied in the
 // epilogue of the pass that completes its gradient.  Weight gradients use sr_conv3x3_wgrad_f32.
+#include <algorithm>
 #include <vector>
 
 #include "sr_internal.h"
@@ -147,7 +148,7 @@ BwdSpace carve_bwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int 
   B.dtrunk = cv.take((size_t)n * P.nfp * hw);
   for (int i = 0; i < 4; ++i) B.g[i] = cv.take((size_t)n * ctot * hw);
   B.dxin = cv.take((size_t)n * P.cin0_pad * hw);
-  B.slab_bytes = sr_conv3x3_wgrad_slab_bytes(n, 4 * h, 4 * w);
+  B.slab_bytes = std::max(sr_conv3x3_wgrad_slab_bytes(n, 4 * h, 4 * w), sr::rdb_wgrad_slab_bytes_f32(n, h, w, c->num_feat, c->num_grow_ch));
   B.slab = cv.take(B.slab_bytes / sizeof(float));
   B.bytes = cv.off;
   return B;
@@ -654,14 +655,26 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
       float* D = B.g[gi];                  // D[0:nf] = dL/d(block output), written by the previous step 0 / conv_body
       float* Dn = B.g[(gi + 1) & 3];
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
-      rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);  // conv5: dY5 = s5 * D[0:nf]
-      if (rc) return rc;
+      const bool one_launch = sr::rdb_wgrad_f32_enabled();  // the block's five weight gradients as one launch, after its data gradients
+      if (!one_launch) {
+        rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);  // conv5: dY5 = s5 * D[0:nf]
+        if (rc) return rc;
+      }
       for (int sl = 4; sl >= 1; --sl) {  // dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k
         float* dys = D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw;
         rc = step(q, sl, D, P.nfp + (4 - sl) * P.gcp, dys, cfg->num_grow_ch, nullptr, 0.f, nullptr, 0.f,
                   cat + (long long)(P.nfp + (sl - 1) * P.gcp) * hw, gcb);
         if (rc) return rc;
-        rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, dys, cat_ns, 1.f);
+        if (!one_launch) {
+          rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, dys, cat_ns, 1.f);
+          if (rc) return rc;
+        }
+      }
+      if (one_launch) {  // D = [dY5 | dY4 | dY3 | dY2 | dY1] is complete: one ticket for the block
+        hipStream_t ws = lane.hand();
+        rc = sr::rdb_wgrad_f32(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5, accumulate,
+                               B.slab, B.slab_bytes, ws);
+        lane.done(ticket++);
         if (rc) return rc;
       }
       // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)

@@ -38,6 +38,11 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream);
 int wgrad_reduce_rows(const WgradReduce* r, int nrows, hipStream_t stream);
 int rdb_wgrad_bf16(const void* cat, const void* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
                    float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream);
+// wgrad_f32.hip: the five weight gradients of a dense block as one launch + one table-driven reduction (fp32 twin of rdb_wgrad_bf16)
+bool rdb_wgrad_f32_enabled();
+size_t rdb_wgrad_slab_bytes_f32(int n, int h, int w, int nf, int gc);
+int rdb_wgrad_f32(const float* cat, const float* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
+                  float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream);
 // pack_net.hip: one-launch packing of every weight image of a network
 struct PackEntry {
   const float* w[5];  // kind 0/1: w[0] = OIHW weight; kind 2: conv1..conv5 of the dense block

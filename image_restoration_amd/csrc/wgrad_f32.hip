@@ -60,9 +60,11 @@ __device__ __forceinline__ void blds16f(__amdgpu_buffer_rsrc_t rs, unsigned voff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
+// The body of one workgroup: tile group `by` of the launch, column strip / row range `bx` of `nbx`.  A device function so that
+// the single-conv kernel and the dense-block kernel (all weight gradients of a residual dense block in ONE launch, below) share it;
+// the parameter block travels by value (conv_f32.hip: by reference the compiler re-reads fields from the kernel-argument segment).
 template <int CT, int IT, int R, int KT>
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void wgrad_f32_body(const WgradParams p, char* smem, const int bx, const int by, const int nbx) {
   constexpr int P = CT * IT, KS = 4 / P;
   static_assert(R == KS || R == 1, "row split or k-step split");
   constexpr bool ROWSPLIT = (R == KS);
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   const int j = lane & 31, h = lane >> 5;
   const int ct = wave / (IT * KS), it = (wave / KS) % IT, ks = wave % KS;
   // one launch covers a grid of same-shaped (CT x IT) tile groups: blockIdx.y walks them
-  const int grow = blockIdx.y / p.gi, gcol = blockIdx.y - grow * p.gi;
+  const int grow = by / p.gi, gcol = by - grow * p.gi;
   const int cout_tile0 = p.cout_tile0 + grow * CT, cin_tile0 = p.cin_tile0 + gcol * IT;
 
-  int t = blockIdx.x;
+  int t = bx;
   const int rs = t % p.row_splits;
   t /= p.row_splits;
   const int strip = t % p.strips;
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   // write this wave's partial tile:  slab[split][pair][tap][g][lane][4]
   const int pair = ct * IT + it;
   // slab[group][split][pair][tap][1024]; bias partials per cout-group ROW: bslab[row][split][CT][32] (column 0 writes)
-  const long long nsplit = (long long)gridDim.x * KS;
-  const long long split = (long long)blockIdx.x * KS + ks;
-  float* dst = p.slab + (((blockIdx.y * nsplit + split) * P + pair) * (KT * KT)) * 1024 + lane * 4;
+  const long long nsplit = (long long)nbx * KS;
+  const long long split = (long long)bx * KS + ks;
+  float* dst = p.slab + (((by * nsplit + split) * P + pair) * (KT * KT)) * 1024 + lane * 4;
 #pragma unroll
   for (int tap = 0; tap < KT * KT; ++tap)
 #pragma unroll
@@ -249,6 +251,39 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
   }
 }
 
+template <int CT, int IT, int R, int KT>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_f32_body<CT, IT, R, KT>(p, smem, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// Every weight gradient of a residual dense block (rrdbnet_arch.py:21-25: five convs = up to kMaxSub same-shaped tile-group sets of
+// four shapes) as ONE launch: blockIdx.y walks the tile groups of all sets, blockIdx.x the column strips / row ranges (the same
+// for every set).  The sets are what run_groups<3> would launch one by one — each followed by its own two reduction launches and
+// each cut into >= 512 workgroups so that it fills the chip ALONE.  Together they fill it with a quarter of the row splits, i.e. a
+// quarter of the partial tiles written to and read back from the slab (which, not the MFMAs, is what a weight gradient of a 32x32
+// patch costs), and one table-driven reduction serves all sets.
+constexpr int kMaxSub = 12;
+struct WgradMulti {
+  WgradParams sub[kMaxSub];
+  int y0[kMaxSub + 1];   // first blockIdx.y of each set
+  int variant[kMaxSub];  // 0: <2,2>  1: <2,1>  2: <1,4>  3: <1,2>  4: <1,1>
+  int nsub;
+};
+__global__ __launch_bounds__(256) void wgrad_f32_rdb_kernel(const WgradMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int s = 0;
+  while (s + 1 < m.nsub && (int)blockIdx.y >= m.y0[s + 1]) ++s;
+  const int by = blockIdx.y - m.y0[s];
+  switch (m.variant[s]) {
+    case 0: wgrad_f32_body<2, 2, 1, 3>(m.sub[s], smem, blockIdx.x, by, gridDim.x); break;
+    case 1: wgrad_f32_body<2, 1, 1, 3>(m.sub[s], smem, blockIdx.x, by, gridDim.x); break;
+    case 2: wgrad_f32_body<1, 4, 1, 3>(m.sub[s], smem, blockIdx.x, by, gridDim.x); break;
+    case 3: wgrad_f32_body<1, 2, 1, 3>(m.sub[s], smem, blockIdx.x, by, gridDim.x); break;
+    default: wgrad_f32_body<1, 1, 1, 3>(m.sub[s], smem, blockIdx.x, by, gridDim.x); break;
+  }
+}
+
 // Slab reduction, two deterministic stages.
 // Stage 1: grid (E4/256, SCH): block (x, sc) sums the splits of chunk sc for 256 float4 columns
 //          (coalesced 4 KiB rows, 8 independent loads in flight per lane) into part[sc][E].
@@ -256,9 +291,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 //          OIHW.  Element (pair, tap, g, lane, e): cout = ct*32 + 8g + 4(lane>>5) + e, cin position = it*32 + (lane&31).
 __device__ __forceinline__ void wgrad_reduce1_body(const float4* __restrict__ slab, float4* __restrict__ part, int e4, int splits,
                                                    int chunk, const float* __restrict__ bslab, float* __restrict__ bpart, int nb,
-                                                   long long stride4, int bstride, int gi, int grp) {
+                                                   long long stride4, int bstride, int gi, int grp, const int sch) {
   // grp = tile group of a multi-group launch: its slab / part blocks follow each other; bias per group row
-  const int sch = gridDim.y;
   slab += (long long)grp * splits * stride4;
   part += (long long)grp * sch * e4;
   if (bslab) {
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float4* __rest
                                                             int e4, int splits, int chunk,
                                                             const float* __restrict__ bslab, float* __restrict__ bpart,
                                                             int nb, long long stride4, int bstride, int gi) {
-  wgrad_reduce1_body(slab, part, e4, splits, chunk, bslab, bpart, nb, stride4, bstride, gi, blockIdx.z);
+  wgrad_reduce1_body(slab, part, e4, splits, chunk, bslab, bpart, nb, stride4, bstride, gi, blockIdx.z, gridDim.y);
 }
 
 // Several independent reductions (the rows of a dense-block weight-gradient launch) in one launch: blockIdx.z = row.
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_rows_kernel(const Reduce1Ro
     }
     return;
   }
-  wgrad_reduce1_body(r.slab, r.part, r.e4, p.splits, p.chunk, nullptr, nullptr, r.nb, r.stride4, r.bstride, 1, 0);
+  wgrad_reduce1_body(r.slab, r.part, r.e4, p.splits, p.chunk, nullptr, nullptr, r.nb, r.stride4, r.bstride, 1, 0, gridDim.y);
 }
 
 struct ReduceParams {
@@ -409,6 +443,38 @@ struct Reduce2Rows {
 };
 __global__ void wgrad_reduce2_rows_kernel(const Reduce2Rows p) { wgrad_reduce2_body(p.row[blockIdx.y], 0); }
 
+// Table-driven form for sets that differ in everything (split count, tile shape, group count): blockIdx.z / blockIdx.y walks the
+// tile groups of all sets (z0 = first group of a set).  Per element the same sums in the same order as the one-set kernels.
+struct TableRow1 {
+  const float4* slab;
+  float4* part;
+  const float* bslab;
+  float* bpart;
+  long long stride4;
+  int e4, nb, bstride, splits, chunk, sch, gi, z0;
+};
+struct ReduceTable1 {
+  TableRow1 row[kMaxSub];
+  int nrows;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce1_table_kernel(const ReduceTable1 t) {
+  int r = 0;
+  while (r + 1 < t.nrows && (int)blockIdx.z >= t.row[r + 1].z0) ++r;
+  const TableRow1 q = t.row[r];
+  if ((int)blockIdx.y >= q.sch || (int)blockIdx.x > (q.e4 + 255) / 256) return;  // the grid is sized for the widest / deepest set
+  wgrad_reduce1_body(q.slab, q.part, q.e4, q.splits, q.chunk, q.bslab, q.bpart, q.nb, q.stride4, q.bstride, q.gi, blockIdx.z - q.z0, q.sch);
+}
+struct ReduceTable2 {
+  ReduceParams row[kMaxSub];
+  int z0[kMaxSub + 1];
+  int nrows;
+};
+__global__ void wgrad_reduce2_table_kernel(const ReduceTable2 t) {
+  int r = 0;
+  while (r + 1 < t.nrows && (int)blockIdx.y >= t.z0[r + 1]) ++r;
+  wgrad_reduce2_body(t.row[r], blockIdx.y - t.z0[r]);
+}
+
 template <int CT, int IT, int R, int KS>
 constexpr int wgrad_lds_bytes() {
   constexpr int XUNITS = ((32 + KS - 1) * (32 * IT / 4) + 63) / 64, YUNITS = 4 * CT;
@@ -419,6 +485,100 @@ struct TapMap {
   int kdim, t_mul, dy_off, dx_off;
 };
 
+int g_wgrad_target_wgs = 512;  // development switch (sr_dev_set_wgrad_f32_target)
+
+// Collects what run_groups<3> would launch (sr::rdb_wgrad_f32 below) instead of launching it.
+struct RdbCollector {
+  bool dry = true;          // sizes only
+  int rows = 0;             // rows per workgroup of every set (0: the whole image height)
+  char* arena = nullptr;    // slab + partial buffers of all sets
+  size_t arena_bytes = 0, used = 0;
+  WgradMulti m = {};
+  sr::WgradReduce red[kMaxSub];
+  int sch[kMaxSub], chunk[kMaxSub];
+  int lds = 0, total_groups = 0;
+  long long nbx = 0, strips_total = 0;
+  char* take(size_t bytes) {
+    char* p = arena ? arena + used : nullptr;
+    used += sr::align_up(bytes, 256);
+    return p;
+  }
+};
+thread_local RdbCollector* g_collect = nullptr;
+
+template <int CT, int IT>
+constexpr int rdb_variant() {
+  return CT == 2 ? (IT == 2 ? 0 : 1) : (IT == 4 ? 2 : (IT == 2 ? 3 : 4));
+}
+template <int CT, int IT, int R, int KT>
+int collect_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, int grows, int gi, bool want_bias,
+                  const TapMap& tm) {
+  RdbCollector& c = *g_collect;
+  constexpr int P = CT * IT, KS = 4 / P, NT = KT * KT;
+  if (KT != 3 || R != 1 || c.m.nsub >= kMaxSub || !((CT == 2 && IT <= 2) || (CT == 1 && (IT == 4 || IT <= 2)))) {
+    sr::set_error("rdb_wgrad_f32: tile-group set <%d,%d,%d,%d> number %d is not collectable", CT, IT, R, KT, c.m.nsub);
+    return SR_EINVAL;
+  }
+  const int groups = grows * gi, i = c.m.nsub;
+  p.cin_tile0 = cin_tile0;
+  p.cout_tile0 = cout_tile0;
+  p.gi = gi;
+  const int rows = c.rows > 0 ? std::min(c.rows, p.H) : p.H;
+  p.rows_per_wg = rows;
+  p.row_splits = sr::cdiv(p.H, rows);
+  c.strips_total = (long long)d->n * p.strips;
+  const long long nwg = c.strips_total * p.row_splits, splits = nwg * KS;
+  if (c.nbx && c.nbx != nwg) {
+    sr::set_error("rdb_wgrad_f32: sets of one launch must share the strip grid");
+    return SR_EINVAL;
+  }
+  c.nbx = nwg;
+  int sch = (int)std::min<long long>(64, (splits + 15) / 16);
+  const int chunk = (int)((splits + sch - 1) / sch);
+  sch = (int)((splits + chunk - 1) / chunk);
+  p.slab = (float*)c.take((size_t)groups * splits * P * NT * 1024 * sizeof(float));
+  p.bslab = want_bias ? (float*)c.take((size_t)grows * splits * CT * 32 * sizeof(float)) : nullptr;
+  sr::WgradReduce& rr = c.red[i];
+  rr = sr::WgradReduce{};
+  rr.slab = p.slab;
+  rr.bslab = p.bslab;
+  rr.part = (float*)c.take((size_t)groups * sch * P * NT * 1024 * sizeof(float));
+  rr.bpart = (float*)c.take((size_t)grows * sch * CT * 32 * sizeof(float));
+  rr.splits = splits;
+  rr.groups = groups;
+  rr.gi = gi;
+  rr.P = P;
+  rr.IT = IT;
+  rr.CT = CT;
+  rr.ntap = NT;
+  rr.ks = KT;
+  rr.kdim = tm.kdim;
+  rr.t_mul = tm.t_mul;
+  rr.dy_off = tm.dy_off;
+  rr.dx_off = tm.dx_off;
+  rr.cin_tile0 = cin_tile0;
+  rr.cout_tile0 = cout_tile0;
+  rr.cout = d->cout;
+  rr.cin = d->cin;
+  rr.first_seg = d->first_seg;
+  rr.seg = d->seg;
+  rr.seg_pad = 8;
+  rr.scale = d->scale;
+  rr.accumulate = d->accumulate;
+  rr.dw = d->dweight;
+  rr.db = want_bias ? d->dbias : nullptr;
+  c.sch[i] = sch;
+  c.chunk[i] = chunk;
+  c.m.sub[i] = p;
+  c.m.variant[i] = rdb_variant<CT, IT>();
+  c.m.y0[i] = c.total_groups;
+  c.total_groups += groups;
+  c.m.y0[i + 1] = c.total_groups;
+  c.m.nsub = i + 1;
+  c.lds = std::max(c.lds, wgrad_lds_bytes<CT, IT, R, KT>());
+  return SR_OK;
+}
+
 template <int CT, int IT, int R, int KT>
 int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, int cin_tile0, int grows, int gi, float* slab,
                  float* bslab, bool want_bias, const TapMap& tm, hipStream_t stream) {
@@ -427,6 +587,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   // and two reduce launches per group.
   constexpr int P = CT * IT, KS = 4 / P, NT = KT * KT;
   constexpr int lds = wgrad_lds_bytes<CT, IT, R, KT>();
+  if (g_collect) return collect_group<CT, IT, R, KT>(d, p, cout_tile0, cin_tile0, grows, gi, want_bias, tm);
   const int groups = grows * gi;
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
@@ -434,7 +595,7 @@ int launch_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0, 
   // rows per workgroup: aim at >= 512 workgroups (2 per CU), multiple of R, at least 4R rows to amortise the prologue
   const long long strips_total = (long long)d->n * p.strips;
   int rows = p.H;
-  while (rows > 4 * R && strips_total * sr::cdiv(p.H, rows) * groups < 512) rows = (rows + 1) / 2;
+  while (rows > 4 * R && strips_total * sr::cdiv(p.H, rows) * groups < g_wgrad_target_wgs) rows = (rows + 1) / 2;
   rows = (rows + R - 1) / R * R;
   p.rows_per_wg = rows;
   p.row_splits = sr::cdiv(p.H, rows);
@@ -738,6 +899,173 @@ int fill_wgrad(const sr_conv3x3_wgrad_desc* d, WgradParams* pp, const char* who)
 
 }  // namespace
 
+namespace {
+int g_rdb_wgrad_f32 = 1;          // development switch (sr_dev_set_rdb_wgrad_f32): 0 = one launch + one reduction per tile-group set
+int g_rdb_wgrad_f32_target = 768; // workgroups of the dense-block launch the row split aims at (3 per CU)
+
+// Runs run_groups<3> for the five convs of a dense block with the collector installed: nothing is launched.
+int rdb_collect(RdbCollector& c, const float* cat, const float* D, long long ns, int n, int h, int w, int nf, int gc,
+                float* const* dparams, float scale5, int accumulate) {
+  const int nfp = (nf + 7) / 8 * 8, gcp = (gc + 7) / 8 * 8;
+  const long long hw = (long long)h * w;
+  static float dummy;  // dry runs: fill_wgrad wants non-null pointers, nothing dereferences them
+  struct Guard {
+    RdbCollector* prev;
+    ~Guard() { g_collect = prev; }
+  } guard{g_collect};
+  g_collect = &c;
+  for (int k = 5; k >= 1; --k) {
+    float* dw = dparams ? dparams[2 * (k - 1)] : &dummy;
+    float* db = dparams ? dparams[2 * (k - 1) + 1] : &dummy;
+    if (!dw) continue;  // frozen conv
+    sr_conv3x3_wgrad_desc d = {};
+    d.x = cat ? cat : &dummy;
+    d.x_img_stride = ns;
+    d.cin = nf + (k - 1) * gc;
+    d.first_seg = nf;
+    d.seg = gc;
+    d.cin_pad = sr_conv3x3_cin_pad(d.cin, nf, gc);
+    d.in_h = h;
+    d.in_w = w;
+    d.dy = D ? (k == 5 ? D : D + (long long)(nfp + (4 - k) * gcp) * hw) : &dummy;
+    d.dy_img_stride = ns;
+    d.cout = k == 5 ? nf : gc;
+    d.n = n;
+    d.scale = k == 5 ? scale5 : 1.f;
+    d.dweight = dw;
+    d.dbias = db;
+    d.accumulate = accumulate;
+    d.slab = &dummy;
+    d.slab_bytes = (size_t)1 << 44;  // the collector's arena is what is checked
+    WgradParams p;
+    p = WgradParams{};
+    p.zero = sr::zero_line();
+    p.x = d.x;
+    p.dy = d.dy;
+    p.x_ns = d.x_img_stride;
+    p.dy_ns = d.dy_img_stride;
+    p.x_h = h;
+    p.x_w = w;
+    p.cout_blocks = (d.cout + 7) / 8;
+    p.src_mul = 1;
+    p.H = p.vH = h;
+    p.W = p.vW = w;
+    p.tap_oy = p.tap_ox = -1;
+    p.cin_blocks = d.cin_pad / 8;
+    p.strips = sr::cdiv(w, 32);
+    const TapMap tm = {3, 1, 0, 0};
+    if (int rc = run_groups<3>(&d, p, d.cin_pad, tm, true, nullptr)) return rc;
+  }
+  return SR_OK;
+}
+
+// Rows per workgroup: halve from the whole image while the launch has fewer workgroups than the target.
+int rdb_rows(const RdbCollector& whole, int h) {
+  int rows = h;
+  while (rows > 4 && whole.strips_total * sr::cdiv(h, rows) * whole.total_groups < g_rdb_wgrad_f32_target) rows = (rows + 1) / 2;
+  return rows;
+}
+}  // namespace
+
+namespace sr {
+bool rdb_wgrad_f32_enabled() { return g_rdb_wgrad_f32 != 0; }
+
+size_t rdb_wgrad_slab_bytes_f32(int n, int h, int w, int nf, int gc) {
+  if (n <= 0 || h <= 0 || w <= 0 || nf <= 0 || gc <= 0) return 0;
+  RdbCollector whole;
+  if (rdb_collect(whole, nullptr, nullptr, 0, n, h, w, nf, gc, nullptr, 1.f, 0)) return 0;
+  RdbCollector c;
+  c.rows = rdb_rows(whole, h);
+  if (rdb_collect(c, nullptr, nullptr, 0, n, h, w, nf, gc, nullptr, 1.f, 0)) return 0;
+  return c.used + 4096;
+}
+
+// The five weight gradients of one residual dense block (rrdbnet_arch.py:21-25) from its concat buffer `cat` = [x|x1..x4] and its
+// gradient concat buffer D = [dY5|dY4|dY3|dY2|dY1] (both CB8, image stride ns) as ONE launch + ONE table-driven reduction.
+// dparams[2k], [2k+1] = dweight / dbias of conv k+1 (null weight: skipped); conv5's gradient is scaled by scale5.  Per conv the
+// same products as sr_conv3x3_wgrad_f32; the sums run over fewer, longer row ranges (deterministic, another rounding order).
+int rdb_wgrad_f32(const float* cat, const float* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
+                  float scale5, int accumulate, void* slab, size_t slab_bytes, hipStream_t stream) {
+  if (!cat || !D || !dparams || !slab || ((uintptr_t)cat | (uintptr_t)D | (uintptr_t)slab) % 16 != 0) {
+    set_error("rdb_wgrad_f32: bad argument");
+    return SR_EINVAL;
+  }
+  RdbCollector whole;
+  if (int rc = rdb_collect(whole, cat, D, ns, n, h, w, nf, gc, dparams, scale5, accumulate)) return rc;
+  if (whole.m.nsub == 0) return SR_OK;  // every conv frozen
+  RdbCollector c;
+  c.rows = rdb_rows(whole, h);
+  c.dry = false;
+  c.arena = (char*)slab;
+  c.arena_bytes = slab_bytes;
+  if (int rc = rdb_collect(c, cat, D, ns, n, h, w, nf, gc, dparams, scale5, accumulate)) return rc;
+  if (c.used > slab_bytes) {
+    set_error("rdb_wgrad_f32: slab %zu B too small (need %zu B)", slab_bytes, c.used);
+    return SR_ENOSPACE;
+  }
+  auto kern = wgrad_f32_rdb_kernel;
+  constexpr int lds_all = std::max({wgrad_lds_bytes<2, 2, 1, 3>(), wgrad_lds_bytes<2, 1, 1, 3>(), wgrad_lds_bytes<1, 4, 1, 3>(),
+                                    wgrad_lds_bytes<1, 2, 1, 3>(), wgrad_lds_bytes<1, 1, 1, 3>()});
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds_all)) return rc;
+  const bool prof = prof_on();
+  if (prof) {
+    sr_launch_record r = {};
+    r.kernel_id = 48;
+    r.cin = nf + 4 * gc;
+    r.cout = nf;
+    r.n = n;
+    r.h = h;
+    r.w = w;
+    const double px = (double)n * h * w;
+    double macs = (double)nf * (nf + 4 * gc);
+    for (int k = 1; k <= 4; ++k) macs += (double)gc * (nf + (k - 1) * gc);
+    r.flops = 2.0 * 9 * macs * px;
+    r.bytes = 4.0 * px * 2 * (nf + 4 * gc);  // cat and D read once
+    prof_begin(stream, r);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)c.nbx, (unsigned)c.total_groups), dim3(256), c.lds, stream, c.m);
+  if (prof) prof_end(stream);
+  SR_CHECK_LAUNCH("wgrad_f32_rdb launch");
+  ReduceTable1 t1 = {};
+  ReduceTable2 t2 = {};
+  int max_cols = 0, max_sch = 0, max_e = 0;
+  for (int i = 0; i < c.m.nsub; ++i) {
+    const WgradReduce& q = c.red[i];
+    TableRow1& a = t1.row[i];
+    a.slab = (const float4*)q.slab;
+    a.part = (float4*)q.part;
+    a.bslab = q.bslab;
+    a.bpart = q.bpart;
+    a.e4 = q.P * q.ntap * 256;
+    a.stride4 = a.e4;
+    a.nb = q.CT * 32;
+    a.bstride = q.CT * 32;
+    a.splits = (int)q.splits;
+    a.chunk = c.chunk[i];
+    a.sch = c.sch[i];
+    a.gi = q.gi;
+    a.z0 = c.m.y0[i];
+    t2.row[i] = reduce2_params(q, c.sch[i], q.gi);
+    t2.z0[i] = c.m.y0[i];
+    max_cols = std::max(max_cols, (a.e4 + 255) / 256 + 1);
+    max_sch = std::max(max_sch, a.sch);
+    max_e = std::max(max_e, q.P * q.ntap * 1024);
+  }
+  t1.nrows = t2.nrows = c.m.nsub;
+  t2.z0[c.m.nsub] = c.total_groups;
+  hipLaunchKernelGGL(wgrad_reduce1_table_kernel, dim3(max_cols, max_sch, c.total_groups), dim3(256), 0, stream, t1);
+  SR_CHECK_LAUNCH("wgrad_reduce1_table launch");
+  hipLaunchKernelGGL(wgrad_reduce2_table_kernel, dim3((max_e + 255) / 256, c.total_groups), dim3(256), 0, stream, t2);
+  SR_CHECK_LAUNCH("wgrad_reduce2_table launch");
+  return SR_OK;
+}
+}  // namespace sr
+
+extern "C" void sr_dev_set_rdb_wgrad_f32(int on, int target_wgs) {
+  g_rdb_wgrad_f32 = on;
+  if (target_wgs > 0) g_rdb_wgrad_f32_target = target_wgs;
+}
+
 extern "C" int sr_conv3x3_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   WgradParams p;
@@ -787,3 +1115,5 @@ extern "C" int sr_conv4x4s2_wgrad_f32(const sr_conv3x3_wgrad_desc* d, void* stre
   }
   return SR_OK;
 }
+
+extern "C" void sr_dev_set_wgrad_f32_target(int wgs) { g_wgrad_target_wgs = wgs > 0 ? wgs : 512; }

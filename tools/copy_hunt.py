@@ -1,0 +1,36 @@
+"""Which host calls of a training step end in a device copy / fill?  torch.profiler over a few steps of the recipe; prints the
+operator table (CPU side) and the copy / memset rows.  usage: python tools/copy_hunt.py [dtype]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from image_restoration_amd.utils.options import parse
+from image_restoration_amd.models import build_model
+from image_restoration_amd.utils import synth
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+opt = parse(os.path.join(root, 'training_config/train_rrdbnet_esrgan_x4_mi355x.yml'), root, is_train=True)
+opt.update(dist=False, rank=0, world_size=1, num_gpu=1)
+opt['network_g']['compute_dtype'] = dtype
+opt['network_d']['compute_dtype'] = dtype
+model = build_model(opt)
+lq = torch.from_numpy(synth.uniform_input(1, (32, 3, 32, 32))).cuda()
+gt = torch.from_numpy(synth.uniform_input(2, (32, 3, 128, 128))).cuda()
+
+
+def step(i):
+    model.update_learning_rate(i, warmup_iter=-1)
+    model.feed_data({'lq': lq, 'gt': gt})
+    model.optimize_parameters(i)
+
+
+for i in range(1, 4):
+    step(i)
+torch.cuda.synchronize()
+K = 3
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    for i in range(4, 4 + K):
+        step(i)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=45, max_name_column_width=60))

@@ -27,6 +27,15 @@ if os.environ.get('ROWS8'):   # development: 0 = the fused dense block on 16-row
     from image_restoration_amd import _lib as _l
     _l.load().sr_dev_set_fused_rows8.argtypes = [_C.c_int]
     _l.load().sr_dev_set_fused_rows8(int(os.environ['ROWS8']))
+if os.environ.get('WGRAD_TARGET'):   # development: workgroups per fp32 weight-gradient launch the row split aims at
+    from image_restoration_amd import _lib as _l2
+    _l2.load().sr_dev_set_wgrad_f32_target(int(os.environ['WGRAD_TARGET']))
+if os.environ.get('RDB_WGRAD'):   # development: "0" = fp32 dense-block weight gradients one tile-group set per launch; "1,<wgs>" = target workgroups
+    import ctypes as _C3
+    from image_restoration_amd import _lib as _l3
+    _v = os.environ['RDB_WGRAD'].split(',')
+    _l3.load().sr_dev_set_rdb_wgrad_f32.argtypes = [_C3.c_int, _C3.c_int]
+    _l3.load().sr_dev_set_rdb_wgrad_f32(int(_v[0]), int(_v[1]) if len(_v) > 1 else 0)
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ))).cuda()
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ))).cuda()
