@@ -166,10 +166,12 @@ namespace {
 // One watch per DEVICE for the whole process (mutex-guarded): autograd runs the backward drivers on its own thread, and a word those
 // queue must be seen by sr_chain_watchdog() on the caller's thread.
 struct Watch {
+  static constexpr int kSlots = 256;
   int32_t* host = nullptr;  // kSlots pinned words
+  hipEvent_t landed[kSlots] = {};  // recorded behind the copy into a slot: a slot is only reused once its copy has landed
+  bool queued[kSlots] = {};
   int next = 0;
   bool sticky = false;  // a raised word that was about to be overwritten before anybody looked
-  static constexpr int kSlots = 256;
 };
 std::mutex g_watch_mu;
 std::map<int, Watch> g_watch;
@@ -182,18 +184,45 @@ Watch& watch_of_device() {  // g_watch_mu held
   return w;
 }
 }  // namespace
+__device__ __attribute__((aligned(64))) int32_t g_sr_abort_latch[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+namespace {
+__global__ void abort_latch_kernel(const int32_t* __restrict__ word, int32_t* __restrict__ latch) {
+  if (threadIdx.x == 0 && *word != 0) *latch = 1;
+}
+__global__ void abort_latch_clear_kernel(int32_t* __restrict__ latch) {
+  if (threadIdx.x == 0) *latch = 0;
+}
+}  // namespace
 namespace sr {
+const int32_t* abort_latch() {  // device address of the calling thread's current device's latch word
+  static void* cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cache[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_sr_abort_latch)) == hipSuccess) cache[dev] = ptr;
+  }
+  return (const int32_t*)cache[dev];
+}
 void chain_watch(const int32_t* abort_word, hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g_watch_mu);
   Watch& w = watch_of_device();
   if (!w.host || !abort_word) return;
   const int slot = w.next;
   w.next = (w.next + 1) % Watch::kSlots;
+  // The copy queued into this slot kSlots calls ago may still be in flight when the host runs far ahead of the device (no step
+  // synchronises any more): reading and re-arming the slot now could lose a word that lands afterwards.  Wait for THAT copy (rare,
+  // and only when the host is more than kSlots watched launches ahead), then keep what it brought.
+  if (w.queued[slot] && w.landed[slot] && hipEventQuery(w.landed[slot]) != hipSuccess) (void)hipEventSynchronize(w.landed[slot]);
   if (((volatile int32_t*)w.host)[slot] != 0) {  // kSlots copies ago and never checked: keep it
     w.sticky = true;
     w.host[slot] = 0;
   }
   (void)hipMemcpyAsync(w.host + slot, abort_word, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+  if (!w.landed[slot] && hipEventCreateWithFlags(&w.landed[slot], hipEventDisableTiming) != hipSuccess) w.landed[slot] = nullptr;
+  w.queued[slot] = w.landed[slot] && hipEventRecord(w.landed[slot], stream) == hipSuccess;
+  // and the device-side latch: consumers on the stream (the optimiser) see the fact without the host
+  hipLaunchKernelGGL(abort_latch_kernel, dim3(1), dim3(64), 0, stream, abort_word, (int32_t*)sr::abort_latch());
 }
 int chain_check(const char* who) {
   std::lock_guard<std::mutex> lk(g_watch_mu);
@@ -214,6 +243,19 @@ int chain_check(const char* who) {
 }
 }  // namespace sr
 extern "C" int sr_chain_watchdog(void) { return sr::chain_check("sr_chain_watchdog"); }
+extern "C" const int32_t* sr_abort_latch(void) { return sr::abort_latch(); }
+// Development hook (tests): raise the device latch from a device word WITHOUT the host-side copy, i.e. the window in which the
+// device knows of a time-out and the host does not yet.
+extern "C" void sr_dev_abort_latch_from(const int32_t* word, void* stream) {
+  hipLaunchKernelGGL(abort_latch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, (int32_t*)sr::abort_latch());
+}
+extern "C" int sr_abort_latch_clear(void* stream) {
+  int32_t* latch = (int32_t*)sr::abort_latch();
+  SR_CHECK_ARG(latch, "sr_abort_latch_clear: no latch on this device");
+  hipLaunchKernelGGL(abort_latch_clear_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, latch);
+  SR_CHECK_LAUNCH("abort_latch_clear");
+  return SR_OK;
+}
 // Development hook (tests): queue a copy of one device word the way the network drivers queue their abort words.
 extern "C" void sr_dev_chain_watch(const int32_t* word, void* stream) { sr::chain_watch(word, (hipStream_t)stream); }
 

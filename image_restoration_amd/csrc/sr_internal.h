@@ -66,6 +66,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes);
 // capi.hip: hand-off watchdog of the dense-block launches (asynchronous copy of a sync block's abort word / check of earlier copies)
 void chain_watch(const int32_t* abort_word, hipStream_t stream);
 int chain_check(const char* who);
+const int32_t* abort_latch();  // device word raised behind a dense-block launch whose abort word went up (sr_abort_latch)
 int chain_mode();      // conv_bf16.hip: sr_set_conv_chain's value
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; 0 = the path's own default)
 // Side streams + fork / join events of the calling thread for the grouped forward (created once per device).

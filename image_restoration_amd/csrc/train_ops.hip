@@ -330,8 +330,13 @@ __global__ void fill_scaled_kernel(const float* __restrict__ g, const float* __r
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float grad_scale) {
+                            float bc1, float bc2_sqrt, float grad_scale, const int32_t* __restrict__ abort_word,
+                            int32_t* __restrict__ skipped) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (abort_word && *abort_word != 0) {  // a launch of this step timed out: its gradients are invalid, the state stays as it is
+    if (i == 0 && skipped) *skipped += 1;
+    return;
+  }
   if (i >= n) return;
   float gi = g[i] * grad_scale;
   const float pi = p[i];
@@ -343,8 +348,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
-__global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b, long long n) {
+__global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, float b, long long n,
+                             const int32_t* __restrict__ abort_word) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (abort_word && *abort_word != 0) return;
   if (i < n) dst[i] = a * dst[i] + b * src[i];
 }
 
@@ -917,20 +924,20 @@ extern "C" int sr_fill_scaled_f32(const float* gout, const float* s, float scale
 
 extern "C" int sr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                                void* stream_) {
+                                const int32_t* abort_word, int32_t* skipped, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "sr_adam_step_f32: bad argument");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long long)n, lr,
-                     beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, abort_word, skipped);
   SR_CHECK_LAUNCH("adam");
   return SR_OK;
 }
 
-extern "C" int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, void* stream_) {
+extern "C" int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, const int32_t* abort_word, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SR_CHECK_ARG(dst && src && n > 0, "sr_axpby_f32: bad argument");
-  hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, stream, dst, src, a, b, (long long)n);
+  hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, stream, dst, src, a, b, (long long)n, abort_word);
   SR_CHECK_LAUNCH("axpby");
   return SR_OK;
 }

@@ -237,10 +237,12 @@ struct StatTable {
   StatRow row[kMaxLayers];
   float momentum;
   int bump;  // added to num_batches_tracked
+  const int32_t* abort_word;  // sr_abort_latch(): statistics of a forward behind a timed-out launch are not folded in
 };
 // running = (1 - momentum) * running + delta with delta = momentum * batch statistic: the fused update of the BatchNorm launches
 // (train_ops.hip bn_finalize_kernel, bn_small.h) split at its `+`.
 __global__ void vgg_apply_stats_kernel(const StatTable t) {
+  if (t.abort_word && *t.abort_word != 0) return;
   const StatRow r = t.row[blockIdx.y];
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch < r.c) {
@@ -293,6 +295,7 @@ int apply_stats(const Plan& P, const char* saved, void* const* host_buffers, int
   }
   t.momentum = kMomentum;
   t.bump = bump;
+  t.abort_word = sr::abort_latch();
   hipLaunchKernelGGL(vgg_apply_stats_kernel, dim3(sr::cdiv(maxc, 256), P.nbn), dim3(256), 0, stream, t);
   SR_CHECK_LAUNCH("vgg_apply_stats launch");
   return SR_OK;

@@ -100,6 +100,26 @@ class BaseModel:
                 watchdog.verify('get_current_log', synchronize=False)   # numbers of a step that timed out must not reach the log
         return self.log_dict
 
+    def recover_from_timeout(self):
+        """After ``optimize_parameters`` / ``get_current_log`` / ``save`` raised the watchdog's SrHipError (a fused dense-block
+        launch timed out: a shared or partitioned GPU).  The optimiser and EMA kernels of the affected steps refused to run ON THE
+        DEVICE (sr_abort_latch), so parameters, Adam moments and the EMA shadow are those of the last good step.  This puts the
+        host side back in line — step counts of the optimisers, the device latch, the watchdog's record — switches this process
+        to the chain launch (no co-residency needed, same bits) and returns the number of optimiser steps that were refused per
+        network.  The caller repeats those iterations; no checkpoint reload is needed."""
+        from .. import _lib, watchdog
+        lib = _lib.load()
+        torch.cuda.synchronize()
+        refused = {label: pack.adam.take_back_skipped() for label, pack in self.packs.items() if pack.adam is not None}
+        _lib.check(lib.sr_abort_latch_clear(torch.cuda.current_stream().cuda_stream), 'sr_abort_latch_clear')
+        torch.cuda.synchronize()
+        lib.sr_chain_watchdog()            # the record of the time-out that was just handled
+        _lib.check(lib.sr_set_conv_chain(2), 'sr_set_conv_chain')
+        self._log_staged = None
+        self.logger.warning(f'recovered from a dense-block time-out: optimiser steps refused on the device {refused}; this process '
+                            'uses the chain launch from now on')
+        return refused
+
     # ------------------------------------------------------------------ networks
     def adopt(self, label, net, weights_key=None, shadow_key=None):
         """Puts ``net`` on the device, loads ``path.pretrain_network_<label>`` when given and registers the pack.

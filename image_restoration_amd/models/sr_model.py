@@ -104,8 +104,9 @@ class SRModel(BaseModel):
     def finish_step(self, book):
         self.stage_loss_dict(book.entries)   # read back by get_current_log(): no host synchronisation inside a step
         if self.device.type == 'cuda':
-            # (without a synchronisation: reports what the abort words copied behind EARLIER launches say — a time-out surfaces one
-            # step later at the latest, and at every hand-over: get_current_log, save, test)
+            # (without a synchronisation: reports what the abort words copied behind EARLIER launches say — a time-out surfaces
+            # a step or two later, and at every hand-over: get_current_log, save, test.  The state stays valid meanwhile: the Adam
+            # and EMA kernels of a step whose launches timed out see the device latch and refuse — BaseModel.recover_from_timeout)
             watchdog.verify('optimize_parameters', synchronize=False)
         if self.ema_decay > 0:
             self.gen.blend_shadow(self.ema_decay)

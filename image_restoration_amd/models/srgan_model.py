@@ -146,5 +146,8 @@ class SRGANModel(SRModel):
 
     # ------------------------------------------------------------------ files
     def save(self, epoch, current_iter):
+        if self.device.type == 'cuda':
+            from .. import watchdog
+            watchdog.verify('save')   # before ANY file of this checkpoint: net_d_<iter>.pth must not appear behind a timed-out step
         self.save_network(self.net_d, 'net_d', current_iter)
         super().save(epoch, current_iter)

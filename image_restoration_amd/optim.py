@@ -61,6 +61,9 @@ class FlatAdam:
         self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False)]
         self.step_count = 0
+        # steps the fused kernel refused on the device because a launch behind their gradients had timed out (sr_abort_latch):
+        # parameters and moments are untouched by those, take_back_skipped() takes them out of step_count again
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == 'cuda' else None
         self.modules = list(modules)
         for m in self.modules:
             # generator: let the fused backward accumulate straight into the arena
@@ -96,9 +99,21 @@ class FlatAdam:
         with torch.cuda.device(self.device):
             _lib.check(lib.sr_adam_step_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                             self.exp_avg_sq.data_ptr(), self.numel, self.step_count, g['lr'], g['betas'][0],
-                                            g['betas'][1], g['eps'], g['weight_decay'], grad_scale,
-                                            torch.cuda.current_stream(self.device).cuda_stream), 'sr_adam_step_f32')
+                                            g['betas'][1], g['eps'], g['weight_decay'], grad_scale, lib.sr_abort_latch(),
+                                            self.skipped.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+                       'sr_adam_step_f32')
         self._invalidate()
+
+    def take_back_skipped(self):
+        """After a time-out was reported: how many of the steps issued since were refused on the device (their bias-correction
+        count is taken back, so the next real step continues the sequence).  Synchronises."""
+        if self.skipped is None:
+            return 0
+        n = int(self.skipped.item())
+        if n:
+            self.step_count -= n
+            self.skipped.zero_()
+        return n
 
     def _invalidate(self):
         self._epoch[0] += 1
@@ -142,7 +157,7 @@ def ema_update(ema_opt_or_flat, src_flat, decay, modules=()):
     assert dst.numel() == src_flat.numel()
     with torch.cuda.device(dst.device):
         _lib.check(lib.sr_axpby_f32(dst.data_ptr(), src_flat.data_ptr(), float(decay), float(1.0 - decay), dst.numel(),
-                                    torch.cuda.current_stream(dst.device).cuda_stream), 'sr_axpby_f32')
+                                    lib.sr_abort_latch(), torch.cuda.current_stream(dst.device).cuda_stream), 'sr_axpby_f32')
     for m in modules:
         if hasattr(m, 'invalidate_packed'):
             m.invalidate_packed()

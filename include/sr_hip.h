@@ -268,6 +268,13 @@ int sr_set_conv_chain(int enabled);
  * same check when they are entered (on the abort words they copied to pinned host memory behind their earlier launches, without
  * synchronising), so a time-out surfaces on the next call at the latest; call this after a synchronisation to cover the work before it. */
 int sr_chain_watchdog(void);
+/* The same fact ON THE DEVICE, for consumers that must not wait for the host to notice: one int32 per device (the calling thread's
+ * current device) that the whole-network drivers raise, by a one-wave launch behind their dense-block launches, when a launch's
+ * abort word went up.  It stays raised until sr_abort_latch_clear (stream-ordered).  sr_adam_step_f32 / sr_axpby_f32 take it as
+ * their abort_word: a training step whose launches timed out then leaves parameters, moments and the EMA shadow exactly as they
+ * were, the host's check raises at the next hand-over, and the job can go on from intact state after sr_set_conv_chain(2). */
+const int32_t* sr_abort_latch(void);
+int sr_abort_latch_clear(void* stream);
 /* fp32 twin: same contract and sync block layout; the calls that share a block must be chains of the same shape (cout of every
  * conv), and a block is used by one precision at a time. */
 int sr_conv3x3_chain_f32(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream);
@@ -348,11 +355,15 @@ int sr_bce_logits_bwd_f32(const float* x, const float* shift, int64_t n, int tar
 int sr_fill_scaled_f32(const float* gout, const float* s, float scale, float* dx, int64_t n, void* stream);
 
 /* torch.optim.Adam step (base_model.py:78-83; lr/betas from the yml) on flat fp32 arenas; step counts from 1;
- * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+ * abort_word (device int32, may be NULL; normally sr_abort_latch()): when it is non-zero at the time the kernel runs, a launch
+ * behind this step's gradients timed out — parameters and moments are left untouched and *skipped (device int32, may be NULL)
+ * is incremented, so that the host can take the skipped steps back out of its step count when it learns of the time-out. */
 int sr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
-/* dst = a*dst + b*src (EMA: base_model.py:50-57 with a = decay, b = 1-decay). */
-int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, void* stream);
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, const int32_t* abort_word,
+                     int32_t* skipped, void* stream);
+/* dst = a*dst + b*src (EMA: base_model.py:50-57 with a = decay, b = 1-decay); abort_word as above: non-zero = dst stays. */
+int sr_axpby_f32(float* dst, const float* src, float a, float b, int64_t n, const int32_t* abort_word, void* stream);
 
 /* ------------------------------------------------------- whole generator ---- */
 

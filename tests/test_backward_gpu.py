@@ -242,3 +242,66 @@ def test_weight_gradients_on_the_side_lane_equal_the_single_stream_backward_bit_
         assert all(torch.equal(a, b) for a, b in zip(want, grads(-1)))
     finally:
         lib.sr_dev_set_backward_overlap(-1)
+
+
+@pytest.mark.parametrize('cfg,shape', [
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=2, num_grow_ch=32), (4, 3, 32, 32)),   # the recipe's patch
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=1, num_grow_ch=32), (1, 3, 37, 70)),   # ragged, 3 column strips
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=32, num_block=1, num_grow_ch=32), (2, 3, 20, 36)),   # C1's widths
+    (dict(num_in_ch=1, num_out_ch=5, scale=2, num_feat=24, num_block=1, num_grow_ch=16), (1, 1, 18, 22)),   # padded channel counts
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=96, num_block=1, num_grow_ch=48), (2, 3, 16, 16)),   # three cout tiles in conv5
+])
+def test_dense_block_weight_gradients_in_one_launch_equal_the_per_conv_route(cuda, cfg, shape):
+    """fp32 backward: the five weight gradients of a dense block go out as ONE launch + one table-driven reduction
+    (csrc/wgrad_f32.hip rdb_wgrad_f32) instead of one launch + two reductions per tile-group set.  Same products per conv, summed
+    over fewer and longer row ranges: every parameter gradient must agree with the per-conv route (sr_dev_set_rdb_wgrad_f32(0))
+    to fp32 summation noise (1e-5 relative to the tensor's max), dL/dx bit for bit, and both must be reproducible bit for bit."""
+    import ctypes as C
+    from image_restoration_amd import _lib
+    lib = _lib.load()
+    lib.sr_dev_set_rdb_wgrad_f32.argtypes = [C.c_int, C.c_int]
+    lib.sr_dev_set_rdb_wgrad_f32.restype = None
+    net = _net(cfg, 5, cuda).train()
+    x = torch.from_numpy(synth.uniform_input(3, shape)).to(cuda).requires_grad_(True)
+    up = {4: 4, 2: 2, 1: 1}[cfg['scale']]
+    r = torch.from_numpy(synth.signed_input(4, (shape[0], cfg['num_out_ch'], up * shape[2], up * shape[3]))).to(cuda)
+
+    def grads(on):
+        lib.sr_dev_set_rdb_wgrad_f32(on, 0)
+        for p in net.parameters():
+            p.grad = None
+        x.grad = None
+        (net(x) * r).sum().backward()
+        torch.cuda.synchronize()
+        return x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+    try:
+        gx0, g0 = grads(0)
+        gx1, g1 = grads(1)
+        gx2, g2 = grads(1)
+    finally:
+        lib.sr_dev_set_rdb_wgrad_f32(1, 0)
+    assert torch.equal(gx0, gx1)
+    for k in g0:
+        assert torch.equal(g1[k], g2[k]), k
+        assert _rel(g1[k], g0[k].cpu().numpy()) < 1e-5, (k, _rel(g1[k], g0[k].cpu().numpy()))
+
+
+def test_dense_block_one_launch_skips_frozen_convs(cuda):
+    """A conv whose weight needs no gradient (host_dparams entry NULL) is left out of the dense block's launch."""
+    cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=1, num_grow_ch=32)
+    net = _net(cfg, 6, cuda).train()
+    x = torch.from_numpy(synth.uniform_input(3, (2, 3, 16, 16))).to(cuda)
+    net(x).sum().backward()
+    full = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    frozen = ('body.0.rdb2.conv3.weight', 'body.0.rdb2.conv3.bias', 'body.0.rdb1.conv5.weight', 'body.0.rdb1.conv5.bias')
+    named = dict(net.named_parameters())
+    for k in frozen:
+        named[k].requires_grad_(False)
+    net(x).sum().backward()
+    for k, p in named.items():
+        if k in frozen:
+            assert p.grad is None
+        else:
+            assert torch.equal(p.grad, full[k]), k

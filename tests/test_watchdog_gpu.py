@@ -132,8 +132,8 @@ def test_two_processes_sharing_the_gpu_run_the_fused_dense_block_on_tiler_cells(
 
 
 def test_training_step_raises_when_a_launch_timed_out(cuda):
-    """optimize_parameters ends with the loss read-back (a synchronisation): a time-out of the step's launches raises there instead of
-    being logged as a step, and save() refuses to write a checkpoint behind it."""
+    """A time-out of a step's launches raises at the next driver entry / hand-over (optimize_parameters, get_current_log, save)
+    instead of being logged as a step, and save() refuses to write a checkpoint behind it."""
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
     from dp_worker import global_batch, options
     from image_restoration_amd.models import build_model
@@ -148,3 +148,89 @@ def test_training_step_raises_when_a_launch_timed_out(cuda):
     _raise_word(cuda)
     with pytest.raises(_lib.SrHipError, match='timed out'):
         model.save(0, 2)
+
+
+def test_gan_checkpoint_writes_no_discriminator_file_behind_a_timed_out_step(cuda, tmp_path):
+    """SRGANModel.save (ESRGANModel's too) checks the watchdog before its FIRST file: no net_d_<iter>.pth of an invalid step."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+    from dp_worker import global_batch, options
+    from image_restoration_amd.models import build_model
+    opt = options('ESRGANModel', 0, 1, False, bf16=True)
+    opt['path']['models'] = str(tmp_path / 'models')
+    opt['path']['training_states'] = str(tmp_path / 'states')
+    os.makedirs(opt['path']['models']), os.makedirs(opt['path']['training_states'])
+    model = build_model(opt)
+    lq, gt = global_batch(1, 2)
+    model.feed_data({'lq': lq, 'gt': gt})
+    model.optimize_parameters(1)
+    _raise_word(cuda)
+    with pytest.raises(_lib.SrHipError, match='timed out'):
+        model.save(0, 1)
+    assert os.listdir(opt['path']['models']) == [] and os.listdir(opt['path']['training_states']) == []
+    model.recover_from_timeout()
+    _lib.check(_lib.load().sr_set_conv_chain(3), 'sr_set_conv_chain')
+    model.save(0, 1)
+    assert sorted(os.listdir(opt['path']['models'])) == ['net_d_1.pth', 'net_g_1.pth']
+
+
+@pytest.mark.parametrize('mt', ['SRModel', 'ESRGANModel'])
+def test_optimiser_and_ema_refuse_a_timed_out_step_on_the_device_and_training_goes_on(cuda, mt):
+    """The window the host cannot close: the device knows a launch of this step timed out (sr_abort_latch is up), the host has not
+    seen the copied word yet and issues Adam and the EMA blend.  Both kernels must leave parameters, moments and the EMA shadow
+    bitwise unchanged and count the refusal; after recover_from_timeout() the repeated iteration gives exactly what an undisturbed
+    run gives (reference contract: base_model.py:78-83 optimiser state, :50-57 EMA)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+    from dp_worker import global_batch, options
+    from image_restoration_amd.models import build_model
+    from image_restoration_amd.utils.options import set_random_seed
+    lib = _lib.load()
+    lib.sr_dev_abort_latch_from.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sr_dev_abort_latch_from.restype = None
+    _lib.check(lib.sr_set_conv_chain(2), 'sr_set_conv_chain')   # both runs on the launch the recovery switches to
+    lq, gt = global_batch(1, 2)
+
+    def build():
+        set_random_seed(7)
+        opt = options(mt, 0, 1, False, bf16=True)
+        opt['train']['ema_decay'] = 0.9
+        return build_model(opt)
+
+    def state(m):
+        out = {}
+        for label, pack in m.packs.items():
+            out[label + '.p'] = pack.adam.flat_p.clone()
+            out[label + '.m'] = pack.adam.exp_avg.clone()
+            out[label + '.v'] = pack.adam.exp_avg_sq.clone()
+            if pack.shadow_arena is not None:
+                out[label + '.ema'] = pack.shadow_arena.clone()
+            for name, buf in pack.net.named_buffers():   # BatchNorm running statistics of the discriminator
+                out[label + '.buf.' + name] = buf.clone()
+        return out
+
+    def step(m, i):
+        m.feed_data({'lq': lq, 'gt': gt})
+        m.optimize_parameters(i)
+
+    clean, hit = build(), build()
+    for i in (1, 2, 3):
+        step(clean, i)
+    step(hit, 1)
+    before = state(hit)
+    counts = {k: p.adam.step_count for k, p in hit.packs.items()}
+    word = torch.ones(4, dtype=torch.int32, device=cuda)
+    lib.sr_dev_abort_latch_from(word.data_ptr(), torch.cuda.current_stream().cuda_stream)   # device only: the host sees nothing
+    step(hit, 2)                        # issued in full, refused on the device
+    torch.cuda.synchronize()
+    after = state(hit)
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    assert all(int(p.adam.skipped.item()) == 1 for p in hit.packs.values())
+    refused = hit.recover_from_timeout()
+    assert refused == {k: 1 for k in hit.packs} and {k: p.adam.step_count for k, p in hit.packs.items()} == counts
+    step(hit, 2)
+    step(hit, 3)
+    torch.cuda.synchronize()
+    want, got = state(clean), state(hit)
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    assert hit.get_current_log() == clean.get_current_log()
