@@ -194,7 +194,7 @@ def roofline_of(ks, peak_tflops, suffix=''):
     common = {'traffic': traffic, 'traffic_source': src, 'kernel': k0['kernel'], 'avg_launch_ms': k0['avg_ms'],
               'avg_launch_ms_note': 'HIP events around each launch on its stream minus the cost of an empty event bracket (%.4f ms, measured in '
                                     'this run); bracketed raw average %.5f ms' % (k0['event_bracket_ms'], k0['avg_ms_bracketed']),
-XX: round(k0['total_ms'] / sum(k['total_ms'] for k in ks), 4),
+              'launches': k0['launches'], 'share_of_profiled_time': round(k0['total_ms'] / sum(k['total_ms'] for k in ks), 4),
               'mfma_util_pmc_stored': mfma_pmc, 'event_bracket_calibration': _BRACKET_SPREAD,
               'frac_from_raw_brackets': round(max(k0['tflops'] / peak_tflops, k0['hbm_frac']) * k0['avg_ms'] / k0['avg_ms_bracketed'], 4)}
     if peak_tflops == PEAK_BF16_TFLOPS:
