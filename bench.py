@@ -238,6 +238,8 @@ def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dty
         raise SystemExit('VGGStyleDiscriminator128 needs 128x128 inputs: --lq 32, or --disc unet')
     else:
         opt['network_d']['compute_dtype'] = d_dtype
+    if os.environ.get('SR_BENCH_OVERLAP_G') == '0':   # tuning: G's optimiser step (and its weight gradients) before the critic phase
+        opt['train']['overlap_g_wgrad'] = False
     if os.environ.get('SR_BENCH_REUSE_D') == '0':   # tuning: every discriminator call of a step runs its own forward
         opt['train']['reuse_d_forwards'] = False
     set_random_seed(opt['manual_seed'] + rank)   # like parse_options: ranks start different, the model aligns its replicas
@@ -322,12 +324,13 @@ def measure_tiled(net, world, rank, dev, dist, backend, *, dtype, steps, warmup,
         'lr_megapixels_per_sec': round(steps * H * W / dt / 1e6, 3)}
     if profile and world == 1:
         peak = PEAK_F32_TFLOPS if dtype == 'fp32' else PEAK_BF16_TFLOPS
-        quarter = img[:, :, :1024, :min(W, 512 * max(2, tile_batch // 2))].contiguous()  # whole 512x512 cells of the frame: its launch shapes
-        ks = profile_launches(lambda: tiled_forward(net, quarter, tile=512, pad=16, scale=4, max_batch=tile_batch, out_dtype=torch.uint8), peak)
+        ks = profile_launches(step, peak)      # the WHOLE frame once more, every launch bracketed (not a corner of it)
         torch.cuda.synchronize()
         res['roofline'] = roofline_of(ks, peak, '_tiled')  # no stored counters at the tiler's launch sizes: traffic null
-        res['roofline']['note'] = 'kernel table from a %dx%d corner of the frame (whole cells, at most %d per forward: the launch shapes of the frame)' \
-            % (quarter.shape[2], quarter.shape[3], tile_batch)
+        res['roofline']['note'] = 'kernel table of one whole frame (%d cells, at most %d per forward), launches bracketed one by one' \
+            % (len(plan_tiles(H, W, 512, 16)), tile_batch)
+        res['kernels'] = ks[:5]
+        res['profiled_launch_ms_total'] = round(sum(k['total_ms'] for k in ks), 2)
     del out
     torch.cuda.empty_cache()
     return res
@@ -374,8 +377,8 @@ def secondary_workloads(net, args, world, rank, dev, dist, backend):
     guarded('c2_infer_bf16', infer_bf16)
     guarded('c5_tiled_4k_bf16', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='bf16', steps=2, warmup=1,
                                                       tile_batch=args.tile_batch, profile=True))
-    guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=2, warmup=0,
-                                                      tile_batch=args.tile_batch, profile=False))
+    guarded('c5_tiled_4k_fp32', lambda: measure_tiled(net, world, rank, dev, dist, backend, dtype='fp32', steps=2, warmup=1,
+                                                      tile_batch=args.tile_batch, profile=True))
     net.set_compute_dtype(args.dtype)
     guarded('c3_train_step', lambda: measure_train(world, rank, dev, dist, backend, yml='train_rrdbnet_esrgan_x4_mi355x_bf16_unet.yml',
                                                    dtype='bf16', disc='unet', disc_dtype='bf16', batch=32, lq=128, steps=3, warmup=1,

@@ -136,6 +136,8 @@ SIGNATURES = {
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sr_axpby_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
     'sr_abort_latch': (C.c_void_p, []),
+    'sr_set_backward_wgrad_deferred': (C.c_int, [C.c_int]),
+    'sr_backward_lane_join': (C.c_int, [C.c_void_p]),
     'sr_abort_latch_clear': (C.c_int, [C.c_void_p]),
     'sr_rrdbnet_num_params': (C.c_int, [C.POINTER(RRDBNetCfg)]),
     'sr_rrdbnet_packed_bytes': (C.c_size_t, [C.POINTER(RRDBNetCfg)]),

@@ -8,6 +8,7 @@ modules below only hold parameters; ``RRDBNet.forward`` hands the whole network 
 the current HIP stream.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -39,6 +40,9 @@ class RRDB(nn.Module):
         self.rdb1 = ResidualDenseBlock(num_feat, num_grow_ch)
         self.rdb2 = ResidualDenseBlock(num_feat, num_grow_ch)
         self.rdb3 = ResidualDenseBlock(num_feat, num_grow_ch)
+
+
+_DEBUG_PARAM_LIST = os.environ.get('SR_DEBUG_PACKS') == '1'
 
 
 @ARCH_REGISTRY.register()
@@ -103,6 +107,10 @@ class RRDBNet(nn.Module):
         longer the module's (``load_state_dict(assign=True)``, a re-registered parameter) and by ``_apply`` (``.to()``, ``.cuda()``)."""
         cached = self.__dict__.get('_plist')
         if cached is not None and cached[0] is self.conv_first.weight and cached[-1] is self.conv_last.bias:
+            if _DEBUG_PARAM_LIST:   # SR_DEBUG_PACKS=1: the full walk every time, and say so if the shortcut would have lied
+                fresh = [p for _, p in self.named_parameters()]
+                assert len(fresh) == len(cached) and all(a is b for a, b in zip(fresh, cached)), \
+                    'a parameter in the middle of the network was re-registered: call net._apply(lambda t: t) or invalidate the list'
             return cached
         plist = [p for _, p in self.named_parameters()]
         self.__dict__['_plist'] = plist

@@ -62,6 +62,11 @@ class _RRDBNetFunction(torch.autograd.Function):
             stream = torch.cuda.current_stream().cuda_stream
             # data-gradient weight images (transposed / flipped), cached per parameter version
             packed_dg = net._ensure_packed_dgrad(lib, cfg, stream, bf16)
+            # deferred weight gradients (NetPack.defer_weight_gradients): the call returns with the lane still busy; whoever consumes
+            # the gradient arena joins first (NetPack.update), and what the lane reads stays alive until then
+            defer = bool(bf16 and getattr(net, '_defer_wgrad', False) and getattr(net, '_grad_sink', None) is not None)
+            if bf16:
+                lib.sr_set_backward_wgrad_deferred(int(defer))
             wbytes = (lib.sr_rrdbnet_backward_workspace_bytes_bf16 if bf16 else
                       lib.sr_rrdbnet_backward_workspace_bytes)(C.byref(cfg), n, h, w)
             ws = net._bwd_workspace(wbytes, dev)
@@ -84,9 +89,15 @@ class _RRDBNetFunction(torch.autograd.Function):
                 accumulate = 0
             dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
             bwd = lib.sr_rrdbnet_backward_bf16 if bf16 else lib.sr_rrdbnet_backward_f32
-            _lib.check(bwd(C.byref(cfg), packed_dg.data_ptr(), ctx.saved.data_ptr(), ctx.saved.numel(), dy.data_ptr(), n, h, w,
-                           ptrs, dx.data_ptr() if dx is not None else None, ws.data_ptr(), wbytes, accumulate, stream),
-                       'sr_rrdbnet_backward_' + ('bf16' if bf16 else 'f32'))
+            try:
+                _lib.check(bwd(C.byref(cfg), packed_dg.data_ptr(), ctx.saved.data_ptr(), ctx.saved.numel(), dy.data_ptr(), n, h, w,
+                               ptrs, dx.data_ptr() if dx is not None else None, ws.data_ptr(), wbytes, accumulate, stream),
+                           'sr_rrdbnet_backward_' + ('bf16' if bf16 else 'f32'))
+            finally:
+                if defer:
+                    lib.sr_set_backward_wgrad_deferred(0)
+            if defer:
+                net._lane_holds.append((ctx.saved, ws, packed_dg))   # released by NetPack.update after the join
         ctx.saved = None
         return (None, dx) + tuple(grads)
 

@@ -236,6 +236,10 @@ int chain_check(const char* who) {
       w.host[i] = 0;
     }
   if (!hit) return SR_OK;
+  // The report ends the episode: optimiser steps queued BEFORE this point (the host had not noticed yet) still see the device latch
+  // and refuse; whatever the caller issues after it was told runs normally again.  The null stream orders the clear behind
+  // everything queued so far on the blocking streams (torch's current stream is one of them).
+  if (int32_t* latch = (int32_t*)abort_latch()) hipLaunchKernelGGL(abort_latch_clear_kernel, dim3(1), dim3(64), 0, (hipStream_t) nullptr, latch);
   set_error("%s: an earlier dense-block launch timed out waiting for a neighbour tile; its results were invalid.  The fused kernel "
             "needs about six rows of 16x32 tiles resident at once; if the GPU cannot give this process that many CUs, call "
             "sr_set_conv_chain(2): the chain launch has no such need", who);
@@ -291,6 +295,44 @@ bool WgradLane::begin(hipStream_t caller, bool enable) {
   return true;
 }
 }  // namespace sr
+namespace {
+struct PendingLane {
+  hipEvent_t ev = nullptr;
+  bool armed = false;
+};
+std::mutex g_pending_mu;
+std::map<int, PendingLane> g_pending;  // per device: autograd issues the backward on its own thread, the optimiser joins on another
+}  // namespace
+namespace sr {
+void lane_detach(WgradLane& lane) {
+  if (!lane.on) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  PendingLane& p = g_pending[dev];
+  if (!p.ev && hipEventCreateWithFlags(&p.ev, hipEventDisableTiming) != hipSuccess) p.ev = nullptr;
+  if (p.ev && hipEventRecord(p.ev, lane.side) == hipSuccess) {
+    p.armed = true;
+    lane.on = false;  // no join at the end of the call
+  } else {
+    lane.end();
+  }
+}
+}  // namespace sr
+extern "C" int sr_backward_lane_join(void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  PendingLane& p = g_pending[dev];
+  if (p.armed && p.ev) {
+    if (hipStreamWaitEvent((hipStream_t)stream, p.ev, 0) != hipSuccess) {
+      sr::set_error("sr_backward_lane_join: hipStreamWaitEvent failed");
+      return SR_ELAUNCH;
+    }
+    p.armed = false;
+  }
+  return SR_OK;
+}
 namespace {
 int g_bn_small = 1;
 }

@@ -109,12 +109,19 @@ FwdSpaceH carve_fwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
 }
 
 struct BwdSpaceH {
-  __bf16 *dyl, *a16, *b16, *a4, *b4, *dtrunk, *g[4], *dxin;
+  __bf16 *dyl, *a16, *a16b, *b16, *a4, *b4, *dtrunk, *dxin;
+  std::vector<__bf16*> g;  // gradient concat buffers: a ring of 4, or one per dense block + 2 when the weight gradients are deferred
   void* slab;
   int32_t* sync;  // hand-off words of the transposed dense blocks' chain launches
   size_t sync_ints;
   size_t slab_bytes, bytes;
 };
+// sr_set_backward_wgrad_deferred: the generator's weight gradients run on the lane and the backward call returns WITHOUT waiting
+// for them; nothing on the caller's stream may wait for the lane either, so every buffer a weight gradient reads stays untouched
+// for the rest of the call: one gradient concat buffer per dense block (13.9 GB at batch 32 of 128x128: HBM is 288 GB) and a second
+// 512x512 head buffer.
+int g_deferred_wgrad = 0;
+
 BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, int w, char* base) {
   BwdSpaceH B;
   CarverH cv{base};
@@ -122,11 +129,13 @@ BwdSpaceH carve_bwd_h(const sr_rrdbnet_cfg* c, const NetPlanH& P, int n, int h, 
   const int ctot = P.nfp + 4 * P.gcp;
   B.dyl = cv.take((size_t)n * r16(c->num_out_ch) * hw * 16);
   B.a16 = cv.take((size_t)n * P.nfp * hw * 16);
+  B.a16b = g_deferred_wgrad ? cv.take((size_t)n * P.nfp * hw * 16) : B.a16;
   B.b16 = cv.take((size_t)n * P.nfp * hw * 16);
   B.a4 = cv.take((size_t)n * P.nfp * hw * 4);
   B.b4 = cv.take((size_t)n * P.nfp * hw * 4);
   B.dtrunk = cv.take((size_t)n * P.nfp * hw);
-  for (int i = 0; i < 4; ++i) B.g[i] = cv.take((size_t)n * ctot * hw);
+  const int ng = g_deferred_wgrad ? 3 * c->num_block + 2 : 4;
+  for (int i = 0; i < ng; ++i) B.g.push_back(cv.take((size_t)n * ctot * hw));
   B.dxin = cv.take((size_t)n * P.cin0_pad * hw);
   B.slab_bytes = sr_conv3x3_wgrad_slab_bytes_bf16(n, 4 * h, 4 * w);
   const size_t rdb_bytes = sr_rdb_wgrad_slab_bytes_bf16(n, h, w, c->num_feat, c->num_grow_ch);
@@ -332,6 +341,11 @@ extern "C" size_t sr_rrdbnet_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int
 extern "C" size_t sr_rrdbnet_saved_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
   return fwd_bytes_h(cfg, n, h, w, true);
 }
+extern "C" int sr_set_backward_wgrad_deferred(int on) {
+  g_deferred_wgrad = on ? 1 : 0;
+  return SR_OK;
+}
+
 extern "C" size_t sr_rrdbnet_backward_workspace_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, int h, int w) {
   NetPlanH P;
   if (!make_plan_h(cfg, &P) || n <= 0 || h <= 0 || w <= 0 || h % P.unshuffle || w % P.unshuffle) return 0;
@@ -465,8 +479,10 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   sr::WgradLane lane;
   {
     const int mode = sr::backward_overlap();
-    lane.begin(stream, mode > 0 || (mode < 0 && (long long)n * hw < 256ll * 16 * 32));
+    lane.begin(stream, g_deferred_wgrad || mode > 0 || (mode < 0 && (long long)n * hw < 256ll * 16 * 32));
   }
+  const bool deferred = g_deferred_wgrad && lane.on;  // (off under the launch profiler: everything on the caller's stream)
+  const int ng = (int)B.g.size();
   long long ticket = 0;
   auto wgrad = [&](int ci, const __bf16* xsrc, long long x_ns, int ih, int iw, int ups, const __bf16* dyp, long long dy_ns,
                    float scale) -> int {
@@ -521,10 +537,10 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   // conv_up2 reads up1 through the nearest x2 upsample (:117)
   rc = wgrad(i_up2, S.up1, feat_ns * 4, 2 * h, 2 * w, 1, B.b16, feat_ns * 16, 1.f);
   if (rc) return rc;
-  lane.need(t_hr);  // a16 is written again below: conv_hr's weight gradient has read it
-  rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16, feat_ns * 16, nullptr, 0, 0);  // a16 = dL/d(upsampled up1)
+  if (B.a16b == B.a16) lane.need(t_hr);  // a16 is written again below: conv_hr's weight gradient has read it
+  rc = dgrad(i_up2, B.b16, feat_ns * 16, 4 * h, 4 * w, B.a16b, feat_ns * 16, nullptr, 0, 0);  // a16b = dL/d(upsampled up1)
   if (rc) return rc;
-  rc = sr_upsample2x_bwd_bf16(B.a16, feat_ns * 16, B.a4, feat_ns * 4, S.up1, feat_ns * 4, 0.2f, n, nfb, 2 * h, 2 * w, stream);
+  rc = sr_upsample2x_bwd_bf16(B.a16b, feat_ns * 16, B.a4, feat_ns * 4, S.up1, feat_ns * 4, 0.2f, n, nfb, 2 * h, 2 * w, stream);
   if (rc) return rc;  // a4 = dL/d(conv_up1 pre-activation)
   rc = wgrad(i_up1, S.trunk, feat_ns, h, w, 1, B.a4, feat_ns * 4, 1.f);
   if (rc) return rc;
@@ -575,15 +591,15 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     return SR_ELAUNCH;
   }
   int chain_call = 0;
-  long long block_ticket[4] = {-1, -1, -1, -1};  // lane job that reads B.g[i]
+  std::vector<long long> block_ticket(ng, -1);  // lane job that reads B.g[i]
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const __bf16* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
       const int q = 3 * b + r;
       const __bf16* cat = S.cat[q];
       __bf16* D = B.g[gi];  // D[0:nf] = dL/d(block output)
-      __bf16* Dn = B.g[(gi + 1) & 3];
-      lane.need(block_ticket[(gi + 1) & 3]);  // Dn was the D of the block three steps ago: its weight gradients have read it
+      __bf16* Dn = B.g[(gi + 1) % ng];
+      lane.need(block_ticket[(gi + 1) % ng]);  // ring of 4: Dn was the D of the block three steps ago, its weight gradients have read it
       const float s5 = r == 2 ? 0.04f : 0.2f, sres = r == 2 ? 0.2f : 1.f;
       // The transposed dense block as one chain of five convs over D (sr_conv3x3_chain_bf16: one launch where the shape allows):
       //   dY_sl = lrelu'(x_sl) * sum_{k > sl} W_k[:, x_sl]^T dY_k   for sl = 4..1, each appended to D, then
@@ -601,7 +617,7 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       block_ticket[gi] = ticket;
       lane.done(ticket++);
       if (rc) return rc;
-      gi = (gi + 1) & 3;
+      gi = (gi + 1) % ng;
     }
   }
   // dL/d(conv_first output) = gradient through the body + the long skip (:114)
@@ -615,7 +631,10 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     rc = sr_cb16_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
     if (rc) return rc;
   }
-  lane.end();  // the caller's stream (the optimiser step comes next) waits for the last weight gradient
+  if (deferred)
+    sr::lane_detach(lane);  // the lane's tail is left pending: sr_backward_lane_join makes a stream wait for it
+  else
+    lane.end();  // the caller's stream (the optimiser step comes next) waits for the last weight gradient
   sr::chain_watch(B.sync, stream);
   return SR_OK;
 }

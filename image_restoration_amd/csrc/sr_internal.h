@@ -137,6 +137,9 @@ struct WgradLane {
   }
   ~WgradLane() { end(); }  // error returns included: the caller's stream never runs ahead of work the lane still holds
 };
+// Deferred join (sr_set_backward_wgrad_deferred): leaves what the lane still holds pending in a per-device record instead of making
+// the caller's stream wait for it; sr_backward_lane_join(stream) — any thread — makes `stream` wait for the pending work.
+void lane_detach(WgradLane& lane);
 bool bn_small_enabled();  // capi.hip: sr_dev_set_bn_small (development switch; default on)
 int backward_overlap();  // sr_dev_set_backward_overlap: -1 automatic (small launches only), 0 never, 1 always
 

@@ -228,6 +228,8 @@ class BaseModel:
         net.load_state_dict(blob, strict=strict)
         if hasattr(net, 'invalidate_packed'):
             net.invalidate_packed()
+        from .. import hip_ops
+        hip_ops.invalidate_packs()   # every cached weight image of the process (per-layer caches key on identity + version + epoch)
 
     @master_only
     def save_training_state(self, epoch, current_iter):

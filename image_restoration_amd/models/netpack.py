@@ -70,10 +70,30 @@ class NetPack:
             p.requires_grad = not frozen
 
     def clear_grads(self):
+        self.join_lane()   # (a deferred backward nobody consumed: its lane still adds into the arena)
         self.adam.zero_grad()
+
+    def defer_weight_gradients(self, on=True):
+        """The network's backward may return while its weight gradients still run on the library's second lane
+        (sr_set_backward_wgrad_deferred); ``update`` joins before it touches the gradient arena.  Only for whole-network
+        backward drivers that write into this pack's arena."""
+        self.net._defer_wgrad = bool(on)
+        if not hasattr(self.net, '_lane_holds'):
+            self.net._lane_holds = []
+
+    def join_lane(self):
+        """The current stream waits for the weight gradients a deferred backward left running; what they read is released."""
+        holds = getattr(self.net, '_lane_holds', None)
+        if holds:
+            from .. import _lib
+            dev = self.adam.flat_g.device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().sr_backward_lane_join(torch.cuda.current_stream(dev).cuda_stream), 'sr_backward_lane_join')
+            holds.clear()
 
     def update(self, distributed):
         """Gradient exchange (SUM over ranks, the 1/world of DDP's mean folded into the Adam kernel) + Adam."""
+        self.join_lane()
         factor = self.adam.all_reduce_grads() if distributed else 1.0
         self.adam.step(grad_scale=factor)
 

@@ -50,11 +50,16 @@ class SRGANModel(SRModel):
         # option key beyond the reference's (default on): run a repeated forward of a repeatable discriminator once per step
         self.reuse_d_forwards = bool(cfg.get('reuse_d_forwards', True))
         self._d_kept, self.d_forwards_run = {}, 0
+        # option key beyond the reference's (default on for a bf16 generator): G's weight gradients overlap the critic phase
+        self.overlap_g_wgrad = bool(cfg.get('overlap_g_wgrad', True)) and getattr(self.net_g, 'compute_dtype', 'fp32') == 'bf16' \
+            and self.device.type == 'cuda'
         self.net_d_iters = cfg.get('net_d_iters', 1)
         self.net_d_init_iters = cfg.get('net_d_init_iters', 0)
         self.setup_optimizers()
         self.setup_schedulers()
         self._build_shadow(cfg)
+        if self.overlap_g_wgrad:
+            self.gen.defer_weight_gradients(True)
 
     def setup_optimizers(self):
         self.optimizer_g = self.make_adam(self.gen, self.opt['train']['optim_g'])
@@ -129,6 +134,8 @@ class SRGANModel(SRModel):
         self.content_terms(book)
         book.charge('l_g_gan', self._fool_critic())
         book.objective.backward()
+        if self.overlap_g_wgrad:
+            return True   # G's optimiser step follows the critic phase: its weight gradients are still running beside it
         self.gen.update(self.distributed)
 
     def optimize_parameters(self, current_iter):
@@ -136,11 +143,16 @@ class SRGANModel(SRModel):
         book = LossBook()
         self._d_kept = {}
         self.d_forwards_run = 0   # distinct discriminator forwards this step issued (5 calls per ESRGAN step)
-        self._generator_phase(book, current_iter)
+        g_step_due = self._generator_phase(book, current_iter)
         self.critic.freeze(False)
         self.critic.clear_grads()
         self._critic_phase(book)
         self._d_kept = {}         # D's weights move next: nothing kept survives them
+        if g_step_due:
+            # The reference steps optimizer_g before the critic phase (esrgan_model.py:48); that phase reads self.output (computed
+            # before the step) and D's weights only, so stepping G here gives the same bits — and lets G's weight gradients, which
+            # nothing but this step waits for, run under the critic phase on the second lane.
+            self.gen.update(self.distributed)
         self.critic.update(self.distributed)
         self.finish_step(book)
 

@@ -270,7 +270,9 @@ int sr_set_conv_chain(int enabled);
 int sr_chain_watchdog(void);
 /* The same fact ON THE DEVICE, for consumers that must not wait for the host to notice: one int32 per device (the calling thread's
  * current device) that the whole-network drivers raise, by a one-wave launch behind their dense-block launches, when a launch's
- * abort word went up.  It stays raised until sr_abort_latch_clear (stream-ordered).  sr_adam_step_f32 / sr_axpby_f32 take it as
+ * abort word went up.  It stays raised until the host has REPORTED the time-out (sr_chain_watchdog or a driver's entry check returning
+ * SR_ELAUNCH: the clear is queued on the null stream at that moment, behind everything issued before the report) or until
+ * sr_abort_latch_clear (stream-ordered).  sr_adam_step_f32 / sr_axpby_f32 take it as
  * their abort_word: a training step whose launches timed out then leaves parameters, moments and the EMA shadow exactly as they
  * were, the host's check raises at the next hand-over, and the job can go on from intact state after sr_set_conv_chain(2). */
 const int32_t* sr_abort_latch(void);
@@ -582,6 +584,18 @@ int sr_vgg_apply_stats_bf16(const sr_vgg_cfg* cfg, const void* saved, size_t sav
 int sr_vgg_backward_bf16(const sr_vgg_cfg* cfg, const void* packed, const float* const* host_params, const void* saved,
                          size_t saved_bytes, const float* dlogits, int n, int train, float* const* host_dparams, int accumulate,
                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Weight gradients of the generator under the discriminator phase (bf16 backward).  The generator's weight gradients feed only its
+ * optimiser step, and the discriminator phase of an ESRGAN step (esrgan_model.py:51-73) reads self.output and D's weights only, so
+ * nothing between G's backward and G's optimiser step needs them.  With sr_set_backward_wgrad_deferred(1), sr_rrdbnet_backward_bf16
+ * issues them on its second lane and RETURNS WITHOUT WAITING for the lane (its workspace grows: one gradient concat buffer per
+ * dense block instead of a ring of four — query sr_rrdbnet_backward_workspace_bytes_bf16 with the switch in the state the call
+ * will see); dx and the caller's stream are complete as usual.  The caller then owes three things: `saved` and `workspace` stay
+ * untouched, and no other backward of this network is issued, until sr_backward_lane_join(stream) has been called — it makes
+ * `stream` wait for the pending lane work (stream-ordered, no host wait) — and the parameter gradients are consumed on `stream`
+ * after that call only.  Same kernels, same order per weight gradient: results are bit-identical to the undeferred call. */
+int sr_set_backward_wgrad_deferred(int on);
+int sr_backward_lane_join(void* stream);
 
 /* ------------------------------------------------------------ measurement ---- */
 
