@@ -66,7 +66,7 @@ class _RRDBNetFunction(torch.autograd.Function):
             # the gradient arena joins first (NetPack.update), and what the lane reads stays alive until then
             defer = bool(bf16 and getattr(net, '_defer_wgrad', False) and getattr(net, '_grad_sink', None) is not None)
             if bf16:
-                lib.sr_set_backward_wgrad_deferred(int(defer))
+                lib.sr_set_backward_wgrad_deferred(int(getattr(net, '_defer_mode', 1)) if defer else 0)
             wbytes = (lib.sr_rrdbnet_backward_workspace_bytes_bf16 if bf16 else
                       lib.sr_rrdbnet_backward_workspace_bytes)(C.byref(cfg), n, h, w)
             ws = net._bwd_workspace(wbytes, dev)

@@ -342,7 +342,7 @@ extern "C" size_t sr_rrdbnet_saved_bytes_bf16(const sr_rrdbnet_cfg* cfg, int n, 
   return fwd_bytes_h(cfg, n, h, w, true);
 }
 extern "C" int sr_set_backward_wgrad_deferred(int on) {
-  g_deferred_wgrad = on ? 1 : 0;
+  g_deferred_wgrad = on < 0 ? 0 : on > 2 ? 2 : on;  // 2: the dense blocks' weight gradients start behind the call's data-gradient chain
   return SR_OK;
 }
 
@@ -592,6 +592,13 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
   }
   int chain_call = 0;
   std::vector<long long> block_ticket(ng, -1);  // lane job that reads B.g[i]
+  struct Later {
+    const __bf16* cat;
+    const __bf16* D;
+    int q;
+    float s5;
+  };
+  std::vector<Later> later;  // deferred mode 2: the dense blocks' weight gradients, issued behind the end of the data-gradient chain
   for (int b = cfg->num_block - 1; b >= 0; --b) {
     const __bf16* d_rrdb = B.g[gi];  // dL/d(RRDB output)
     for (int r = 2; r >= 0; --r) {
@@ -612,11 +619,15 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
       rc = sr_conv3x3_chain_bf16(dd, 5, B.sync, chain_call++, stream);
       if (rc) return rc;
       // all five weight gradients of the block in one launch (conv5: dY5 = s5 * D[0:nf]); D is complete and stays intact
-      rc = sr::rdb_wgrad_bf16(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5,
-                              accumulate, B.slab, B.slab_bytes, lane.hand());
-      block_ticket[gi] = ticket;
-      lane.done(ticket++);
-      if (rc) return rc;
+      if (deferred && g_deferred_wgrad >= 2) {
+        later.push_back({cat, D, q, s5});  // behind the whole data-gradient chain: under whatever the caller issues next
+      } else {
+        rc = sr::rdb_wgrad_bf16(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5,
+                                accumulate, B.slab, B.slab_bytes, lane.hand());
+        block_ticket[gi] = ticket;
+        lane.done(ticket++);
+        if (rc) return rc;
+      }
       gi = (gi + 1) % ng;
     }
   }
@@ -630,6 +641,15 @@ extern "C" int sr_rrdbnet_backward_bf16(const sr_rrdbnet_cfg* cfg, const void* p
     if (rc) return rc;
     rc = sr_cb16_to_nchw_f32(B.dxin, (long long)P.cin0_pad * hw, dx, n, cfg->num_in_ch, h, w, P.unshuffle, stream);
     if (rc) return rc;
+  }
+  if (!later.empty()) {
+    hipStream_t ws = lane.hand();  // everything the caller's stream got in this call comes first
+    for (const Later& l : later) {
+      rc = sr::rdb_wgrad_bf16(l.cat, l.D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * l.q), l.s5,
+                              accumulate, B.slab, B.slab_bytes, ws);
+      if (rc) return rc;
+    }
+    lane.done(ticket++);
   }
   if (deferred)
     sr::lane_detach(lane);  // the lane's tail is left pending: sr_backward_lane_join makes a stream wait for it

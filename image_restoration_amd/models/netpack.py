@@ -77,7 +77,9 @@ class NetPack:
         """The network's backward may return while its weight gradients still run on the library's second lane
         (sr_set_backward_wgrad_deferred); ``update`` joins before it touches the gradient arena.  Only for whole-network
         backward drivers that write into this pack's arena."""
+        import os
         self.net._defer_wgrad = bool(on)
+        self.net._defer_mode = int(os.environ.get('SR_DEFER_MODE', '1'))   # development: 2 = dense-block weight gradients behind the dgrad chain
         if not hasattr(self.net, '_lane_holds'):
             self.net._lane_holds = []
 

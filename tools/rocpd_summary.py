@@ -84,5 +84,70 @@ if __name__ == '__main__':
         mfma(sys.argv[2], sys.argv[3:])
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'timeline':
+        pass   # defined below
     else:
         traffic(sys.argv[2], sys.argv[3:])
+
+
+def timeline(db, out_txt, marker='adam_kernel'):
+    """Per-queue timeline of the LAST complete training step in a kernel trace (a step = the dispatches between two consecutive
+    last-Adam launches): wall time, busy time per hardware queue (the caller's stream and the library's second lane land on
+    different queues), time during which two queues run kernels at once, and the average duration of the kernels that ran on the
+    second queue — the numbers that say whether work moved under other work or merely beside it."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute('pragma table_info(kernels)').fetchall()]
+    qcol = next((k for k in ('queue_id', 'queue', 'stream_id', 'stream') if k in cols), None)
+    lines = [f'columns of `kernels`: {cols}', f'queue column: {qcol}']
+    if not qcol or 'start' not in cols or 'end' not in cols:
+        open(out_txt, 'w').write('\n'.join(lines) + '\n')
+        print('\n'.join(lines))
+        return
+    rows = c.execute(f'select name, start, end, {qcol} from kernels order by start').fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    # two Adam launches per GAN step (G and D): a step ends at every second one
+    ends = marks[1::2] if len(marks) >= 4 else marks
+    if len(ends) < 2:
+        lines.append('fewer than two steps in the trace')
+        open(out_txt, 'w').write('\n'.join(lines) + '\n')
+        return
+    lo, hi = ends[-2] + 1, ends[-1] + 1
+    step = rows[lo:hi]
+    t0, t1 = min(r[1] for r in step), max(r[2] for r in step)
+    lines.append(f'last step: {len(step)} dispatches, wall {(t1 - t0) / 1e6:.3f} ms, kernel time summed {sum(r[2] - r[1] for r in step) / 1e6:.3f} ms')
+    queues = {}
+    for r in step:
+        queues.setdefault(r[3], []).append(r)
+    for q, rs in sorted(queues.items(), key=lambda kv: -sum(r[2] - r[1] for r in kv[1])):
+        busy = sum(r[2] - r[1] for r in rs)
+        names = {}
+        for r in rs:
+            names[r[0][:60]] = names.get(r[0][:60], 0) + (r[2] - r[1])
+        top = ', '.join(f'{k.split("(")[0][-44:]} {v / 1e6:.2f} ms' for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:3])
+        lines.append(f'queue {q}: {len(rs)} dispatches, busy {busy / 1e6:.3f} ms, first {(rs[0][1] - t0) / 1e6:.3f} ms, last end {(max(r[2] for r in rs) - t0) / 1e6:.3f} ms; {top}')
+    # overlap: sweep
+    ev = []
+    for r in step:
+        ev.append((r[1], 1, r[3]))
+        ev.append((r[2], -1, r[3]))
+    ev.sort()
+    active, last, both, any_ = {}, t0, 0, 0
+    for t, d, q in ev:
+        n_active = sum(1 for v in active.values() if v > 0)
+        if n_active >= 1:
+            any_ += t - last
+        if n_active >= 2:
+            both += t - last
+        last = t
+        active[q] = active.get(q, 0) + d
+    lines.append(f'some queue busy {any_ / 1e6:.3f} ms, two or more queues busy at once {both / 1e6:.3f} ms, idle {(t1 - t0 - any_) / 1e6:.3f} ms')
+    for key in ('wgrad_rdb_bf16', 'rdb_fused'):
+        ds = [r[2] - r[1] for r in step if key in r[0]]
+        if ds:
+            lines.append(f'{key}: {len(ds)} launches, average {sum(ds) / len(ds) / 1e3:.1f} us, total {sum(ds) / 1e6:.2f} ms')
+    open(out_txt, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'timeline':
+    timeline(sys.argv[2], sys.argv[3])
