@@ -901,7 +901,8 @@ int fill_wgrad(const sr_conv3x3_wgrad_desc* d, WgradParams* pp, const char* who)
 
 namespace {
 int g_rdb_wgrad_f32 = 1;          // development switch (sr_dev_set_rdb_wgrad_f32): 0 = one launch + one reduction per tile-group set
-int g_rdb_wgrad_f32_target = 768; // workgroups of the dense-block launch the row split aims at (3 per CU)
+int g_rdb_wgrad_f32_target = 256; // workgroups of the dense-block launch the row split aims at: one per CU (whole 32x32 patches per
+                                  // workgroup: 54.2 ms per recipe step against 55.9 at two row ranges per patch and 59.8 at four)
 
 // Runs run_groups<3> for the five convs of a dense block with the collector installed: nothing is launched.
 int rdb_collect(RdbCollector& c, const float* cat, const float* D, long long ns, int n, int h, int w, int nf, int gc,
