@@ -9,6 +9,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 DT = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 _lib.check(_lib.load().sr_set_forward_groups(G), 'sr_set_forward_groups')
+if os.environ.get('RDB_WGRAD'):   # development: "0" = fp32 dense-block weight gradients one tile-group set per launch; "1,<wgs>" = target workgroups
+    _v = os.environ['RDB_WGRAD'].split(',')
+    _lib.load().sr_dev_set_rdb_wgrad_f32.argtypes = [C.c_int, C.c_int]
+    _lib.load().sr_dev_set_rdb_wgrad_f32(int(_v[0]), int(_v[1]) if len(_v) > 1 else 0)
 cfg = dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32)
 dev = torch.device('cuda')
 net = ira.build_network(dict(type='RRDBNet', **cfg)).to(dev)

@@ -17,7 +17,9 @@ if [ "$STAGE" = all ] || [ "$STAGE" = 1 ]; then
 run ks_default --kernel-trace --stats -d $O/ks_default -- python3 $R/bench.py --no-cpu-baseline
 run ks_fp32 --kernel-trace --stats -d $O/ks_fp32 -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 10
 run ks_bf16 --kernel-trace --stats -d $O/ks_bf16 -- python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --no-secondary --steps 10
+export SR_BENCH_OVERLAP_G=0   # per-kernel durations are only meaningful when launches do not overlap: G's weight gradients on the caller's stream
 run ks_c3 --kernel-trace --stats -d $O/ks_c3 -- python3 $R/bench.py --mode train --dtype bf16 --disc unet --lq 128 --batch 32 --steps 3 --warmup 1
+unset SR_BENCH_OVERLAP_G
 run ks_tiled --kernel-trace --stats -d $O/ks_tiled -- python3 $R/bench.py --mode tiled --dtype bf16 --steps 1 --warmup 1
 run ks_tiled_fp32 --kernel-trace --stats -d $O/ks_tiled_fp32 -- python3 $R/bench.py --mode tiled --dtype fp32 --steps 1 --warmup 1
 run ks_recipe_fp32 --kernel-trace --stats -d $O/ks_recipe_fp32 -- python3 $R/bench.py --mode train --lq 32 --batch 32 --steps 4 --warmup 2 --dtype fp32
@@ -39,6 +41,7 @@ if [ "$STAGE" = all ] || [ "$STAGE" = 2 ]; then
 B32="python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 1"
 B16="python3 $R/bench.py --dtype bf16 --groups 1 --no-cpu-baseline --no-secondary --steps 2 --warmup 1"
 C3="python3 $R/bench.py --mode train --dtype bf16 --disc unet --lq 128 --batch 32 --steps 1 --warmup 1"
+export SR_BENCH_OVERLAP_G=0   # counters per kernel: no second lane
 TL="python3 $R/bench.py --mode tiled --dtype bf16 --steps 1 --warmup 0"
 RF="python3 $R/bench.py --mode train --lq 32 --batch 32 --steps 2 --warmup 1 --dtype fp32"
 for w in f32:"$B32" b16:"$B16" c3:"$C3" tl:"$TL" rf:"$RF"; do
