@@ -108,6 +108,7 @@ struct FwdSpace {
   size_t bytes;
 };
 constexpr int kSyncBlocks = 4;
+int g_group_min_wgs = 512;  // development switch (sr_dev_set_group_min_wgs): workgroups a forward image group keeps per launch
 
 FwdSpace carve_fwd(const sr_rrdbnet_cfg* c, const NetPlan& P, int n, int h, int w, char* base, bool train) {
   FwdSpace W;
@@ -329,7 +330,7 @@ int forward_impl(const sr_rrdbnet_cfg* cfg, const float* packed, const float* x,
   const long long wg_per_image = (long long)sr::cdiv(w, 32) * sr::cdiv(h, 8);
   int groups = sr::forward_groups();
   if (groups == 0) groups = 1;  // fp32 default: no grouping (include/sr_hip.h)
-  while (groups > 1 && (n / groups) * wg_per_image < 512) --groups;
+  while (groups > 1 && (n / groups) * wg_per_image < g_group_min_wgs) --groups;
   if (groups > n) groups = n;
   if (hipMemsetAsync(W.sync, 0, W.sync_ints * kSyncBlocks * sizeof(int32_t), stream) != hipSuccess) {
     sr::set_error("sr_rrdbnet_forward: sync memset failed");
@@ -699,3 +700,5 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
   }
   return SR_OK;
 }
+
+extern "C" void sr_dev_set_group_min_wgs(int wgs) { g_group_min_wgs = wgs > 0 ? wgs : 512; }

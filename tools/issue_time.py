@@ -36,6 +36,12 @@ if os.environ.get('RDB_WGRAD'):   # development: "0" = fp32 dense-block weight g
     _v = os.environ['RDB_WGRAD'].split(',')
     _l3.load().sr_dev_set_rdb_wgrad_f32.argtypes = [_C3.c_int, _C3.c_int]
     _l3.load().sr_dev_set_rdb_wgrad_f32(int(_v[0]), int(_v[1]) if len(_v) > 1 else 0)
+if os.environ.get('FWD_GROUPS'):   # development: "<groups>,<min workgroups per group launch>" for the fp32 forward
+    from image_restoration_amd import _lib as _l4
+    _g = os.environ['FWD_GROUPS'].split(',')
+    _l4.check(_l4.load().sr_set_forward_groups(int(_g[0])), 'sr_set_forward_groups')
+    if len(_g) > 1:
+        _l4.load().sr_dev_set_group_min_wgs(int(_g[1]))
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ))).cuda()
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ))).cuda()
