@@ -121,3 +121,34 @@ def test_argument_errors_are_codes_with_messages_not_crashes():
     good = _lib.RRDBNetCfg(3, 3, 2, 16, 1, 8)
     assert failed(lib.sr_rrdbnet_forward_f32(ctypes.byref(good), 256, 256, 256, 1, 9, 8, 256, 1 << 30, None), 'divisible')
     assert failed(lib.sr_gan_point_loss_fwd_f32(256, 16, 9, 0.0, 1.0, 256, 256, 1 << 20, None), 'bad argument')
+
+
+def test_whole_discriminator_driver_plans_without_a_gpu():
+    """sr_vgg_*: the host-only helpers (plan, sizes) and the argument checks of the drivers — no launch happens."""
+    lib = _lib.load()
+    c128, c256 = _lib.VGGCfg(3, 64, 128), _lib.VGGCfg(3, 64, 256)
+    assert lib.sr_vgg_num_params(ctypes.byref(c128)) == 33 and lib.sr_vgg_num_batchnorm(ctypes.byref(c128)) == 9
+    assert lib.sr_vgg_num_params(ctypes.byref(c256)) == 39 and lib.sr_vgg_num_batchnorm(ctypes.byref(c256)) == 11
+    # the state_dict of the module has exactly those tensors, in that order of kinds
+    net = ira.build_network(dict(type='VGGStyleDiscriminator128', num_in_ch=3, num_feat=64))
+    assert len(list(net.parameters())) == 33 and len(list(net.buffers())) == 27
+    assert [k for k, _ in net.named_parameters()][:5] == ['conv0_0.weight', 'conv0_0.bias', 'conv0_1.weight', 'bn0_1.weight', 'bn0_1.bias']
+    assert [k for k, _ in net.named_parameters()][-4:] == ['linear1.weight', 'linear1.bias', 'linear2.weight', 'linear2.bias']
+    for suffix in ('', '_bf16'):
+        packed = getattr(lib, 'sr_vgg_packed_bytes' + suffix)(ctypes.byref(c128))
+        s1, s2 = (getattr(lib, 'sr_vgg_saved_bytes' + suffix)(ctypes.byref(c128), n) for n in (1, 2))
+        w1 = getattr(lib, 'sr_vgg_workspace_bytes' + suffix)(ctypes.byref(c128), 1)
+        assert packed > 0 and 0 < s1 < s2 < 2 * s1 + (1 << 20) and w1 > 0
+    # fp32 weights of the 128 network: every conv twice (forward + data-gradient image) is at least 2 x the raw conv weights
+    raw = sum(p.numel() for k, p in net.named_parameters() if k.startswith('conv')) * 4
+    assert lib.sr_vgg_packed_bytes(ctypes.byref(c128)) >= 2 * raw
+    assert lib.sr_vgg_num_params(ctypes.byref(_lib.VGGCfg(3, 64, 96))) == 0              # unsupported input size
+    assert lib.sr_vgg_packed_bytes_bf16(ctypes.byref(_lib.VGGCfg(3, 8, 128))) == 0          # bf16 needs num_feat % 16 == 0
+    assert lib.sr_vgg_saved_bytes(ctypes.byref(c128), 0) == 0
+
+    def failed(rc, word):
+        return rc < 0 and word in lib.sr_last_error().decode()
+    assert failed(lib.sr_vgg_forward_f32(ctypes.byref(c128), None, None, None, None, None, 1, 1, None, 0, None, 0, None), 'null')
+    bad = _lib.VGGCfg(3, 64, 100)
+    assert failed(lib.sr_vgg_backward_f32(ctypes.byref(bad), None, None, None, 0, None, 1, 1, None, 0, None, None, 0, None), 'bad configuration')
+    assert failed(lib.sr_adam_step_f32(None, None, None, None, 0, 1, 1e-4, 0.9, 0.99, 1e-8, 0.0, 1.0, None, None, None), 'bad argument')
