@@ -66,14 +66,22 @@ constexpr int kNPhase = 13;
 #define SR_FZ_PERDX 1  // 1: the partial-sum phases advance one tap column per step (62 steps per tile); 0: one chunk per step (34; conv5's last input stays per column: the next tile's read-ahead needs those steps)
 #define SR_FZ_CLAIMLEAD 3  // steps between the ticket atomic and its hand-over
 #endif
+// (SR_FZ_PERDX2: the same switch for the partial-sum phases of TWO accumulator groups only — 18 weight pieces per chunk, two steps'
+// worth fit a ring of 36 — while the three-group phases, 27 pieces per chunk, keep a tap column per step; default = SR_FZ_PERDX)
+#ifndef SR_FZ_PERDX2
+#define SR_FZ_PERDX2 SR_FZ_PERDX
+#endif
+#ifndef SR_FZ_PERDX2B
+#define SR_FZ_PERDX2B SR_FZ_PERDX2
+#endif
 constexpr int kPhase[kNPhase][7] = {{0, 0, 4, 0, 1, 0, 1},                                                          // conv1 x
-                                    {0, 0, 4, 1, 2, SR_FZ_PERDX, 0}, {0, 0, 2, 3, 3, SR_FZ_PERDX, 0},               //   conv2-3 x | conv4-5 x[0,1]
+                                    {0, 0, 4, 1, 2, SR_FZ_PERDX2, 0}, {0, 0, 2, 3, 3, SR_FZ_PERDX, 0},              //   conv2-3 x | conv4-5 x[0,1]
                                     {1, 0, 2, 1, 1, 0, 2},                                                          // conv2 x1
                                     {0, 2, 4, 3, 3, SR_FZ_PERDX, 0}, {1, 0, 2, 2, 1, 0, 0},                         //   conv4-5 x[2,3] | conv3 x1
                                     {2, 0, 2, 2, 1, 0, 3},                                                          // conv3 x2
                                     {1, 0, 2, 3, 3, SR_FZ_PERDX, 0}, {2, 0, 2, 3, 1, 0, 0},                         //   conv4-5 x1 | conv4 x2
                                     {3, 0, 2, 3, 1, 0, 4},                                                          // conv4 x3
-                                    {2, 0, 2, 4, 2, SR_FZ_PERDX, 0}, {3, 0, 2, 4, 2, SR_FZ_PERDX, 0},               //   conv5 x2 | conv5 x3
+                                    {2, 0, 2, 4, 2, SR_FZ_PERDX2B, 0}, {3, 0, 2, 4, 2, SR_FZ_PERDX2B, 0},           //   conv5 x2 | conv5 x3
                                     {4, 0, 2, 4, 2, 1, 5}};                                               // conv5 x4
 #ifndef SR_FZ_PUBLAG
 #define SR_FZ_PUBLAG {4, 2, 2, 3}
