@@ -492,6 +492,10 @@ def main():
     if args.overlap != -1:
         from image_restoration_amd import _lib
         _lib.load().sr_dev_set_backward_overlap(args.overlap)
+    if os.environ.get('SR_DEV_FUSED_ROWS8'):   # tuning: 3 = every fused dense block on 8-row tiles (34 steps per tile)
+        from image_restoration_amd import _lib
+        _lib.load().sr_dev_set_fused_rows8.argtypes = [C.c_int]
+        _lib.load().sr_dev_set_fused_rows8(int(os.environ['SR_DEV_FUSED_ROWS8']))
     if args.chain:
         from image_restoration_amd import _lib
         _lib.check(_lib.load().sr_set_conv_chain(args.chain), 'sr_set_conv_chain')
