@@ -27,6 +27,7 @@ namespace {
 constexpr int kMaxLayers = 12;  // 10 convs of the 128 network, 12 of the 256 one
 constexpr float kSlope = 0.2f, kMomentum = 0.1f, kEps = 1e-5f;
 constexpr int kHidden = 100;  // linear1's width (discriminator_arch.py:45)
+int g_vgg_lane = 1;           // development switch (sr_dev_set_vgg_lane): 0 = the backward's weight gradients on the caller's stream
 
 struct Layer {
   int k;             // 3 or 4
@@ -176,7 +177,9 @@ bool make_plan(const sr_vgg_cfg* c, int n, bool bf16, Plan* P) {
 
 // ---- workspaces -----------------------------------------------------------------------------------------------------
 struct Space {
-  char *A, *B, *Cb;   // activation-gradient ping-pong buffers (+ a third for the bf16 way back through the unshuffle)
+  char *A, *Cb;       // gradient wrt the current activation (+ a second buffer for the bf16 way back through the unshuffle)
+  char* Z[kMaxLayers];  // gradient wrt every conv's result: one buffer per layer, so that the weight gradients, which read them on
+                        // the second lane (sr_internal.h WgradLane), never hold the data-gradient chain up
   char* red;          // reduction scratch of the BatchNorm launches
   size_t red_bytes;
   char* slab;         // weight-gradient slab
@@ -208,7 +211,7 @@ Space carve(const Plan& P, int n, char* base) {
   }
   small += sr::align_up((size_t)kHidden * P.nin1, 64) + 2 * sr::align_up((size_t)kHidden, 64) + 64;  // linear1.{weight,bias}, linear2.{weight,bias}
   W.A = take(big);
-  W.B = take(big);
+  for (int i = 0; i < P.nl; ++i) W.Z[i] = take(act_bytes(P, n, P.L[i].cout, P.L[i].out_s));
   W.Cb = P.bf16 ? take(big) : nullptr;
   W.red_bytes = sr_reduce_workspace_bytes(maxc);
   W.red = take(W.red_bytes);
@@ -471,7 +474,14 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
     SR_TRY(sr_linear_bwd_f32(feat, hp[P.p_l1w], y1, W.dy1, n, P.nin1, kHidden, kSlope, W.dz1, W.dfeat, dw1, db1, stream));
   }
   char* gA = W.A;  // gradient wrt the activation that leaves layer i
-  char* gZ = W.B;  // gradient wrt the conv result of layer i
+  // Weight gradients depend on the data gradients issued so far and feed only the optimiser: they go to the lane (a side stream for
+  // launches of this size; sr_dev_set_backward_overlap 0 = the caller's stream) and are joined at the end of the call.
+  sr::WgradLane lane;
+  {
+    const int mode = sr::backward_overlap();
+    lane.begin(stream, g_vgg_lane && need_p && (mode > 0 || (mode < 0 && (long long)n * P.S * P.S <= 64ll * 128 * 128)));
+  }
+  long long ticket = 0;
   if (!bf)
     SR_TRY(sr_nchw_to_cb8_f32(W.dfeat, (float*)gA, n, P.feat_ch, P.feat_s, P.feat_s, 1, blocks(P.feat_ch), img(P.feat_ch, P.feat_s), stream));
   else
@@ -480,6 +490,7 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
     const Layer& l = P.L[i];
     const int64_t ns = img(l.cout, l.out_s);
     const char* a = saved + l.a_off;
+    char* gZ = W.Z[i];  // gradient wrt the conv result of layer i
     if (l.bn) {
       float* dgamma = need_p ? via_add(l.p_gamma, l.cout) : (float*)W.small;  // (a frozen network: written, never read)
       float* dbeta = need_p ? via_add(l.p_beta, l.cout) : (float*)W.small + sr::align_up((size_t)l.cout, 64);
@@ -541,6 +552,12 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
     }
     // weight gradient
     if (need_p) {
+      hipStream_t ws = lane.hand();
+      struct Done {
+        sr::WgradLane& l;
+        long long k;
+        ~Done() { l.done(k); }
+      } mark{lane, ticket++};
       sr_conv3x3_wgrad_desc g = {};
       g.dy = (const float*)gZ;
       g.dy_img_stride = ns;
@@ -558,7 +575,7 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
         g.in_h = g.in_w = l.in_s;
         g.cin = g.first_seg = l.cin;
         g.dweight = dp[l.p_w];
-        SR_TRY(l.k == 3 ? sr_conv3x3_wgrad_f32(&g, stream) : sr_conv4x4s2_wgrad_f32(&g, stream));
+        SR_TRY(l.k == 3 ? sr_conv3x3_wgrad_f32(&g, ws) : sr_conv4x4s2_wgrad_f32(&g, ws));
       } else if (l.k == 3) {
         g.x = (const float*)src;
         g.x_img_stride = img(l.cin, l.in_s);
@@ -566,7 +583,7 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
         g.in_h = g.in_w = l.in_s;
         g.cin = g.first_seg = l.cin;
         g.dweight = dp[l.p_w];
-        SR_TRY(sr_conv3x3_wgrad_bf16(&g, stream));
+        SR_TRY(sr_conv3x3_wgrad_bf16(&g, ws));
       } else {  // 3x3 gradient of the embedded weight, folded back to 4x4, added at the end
         float* dw3 = small;
         small += sr::align_up((size_t)l.cout * l.cin * 36, 64);
@@ -578,8 +595,8 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
         g.cin = g.first_seg = 4 * l.cin;
         g.dweight = dw3;
         g.accumulate = 0;
-        SR_TRY(sr_conv3x3_wgrad_bf16(&g, stream));
-        SR_TRY(sr_conv4x4s2_weight_as_3x3_f32(dw4, dw3, l.cout, l.cin, 1, stream));
+        SR_TRY(sr_conv3x3_wgrad_bf16(&g, ws));
+        SR_TRY(sr_conv4x4s2_weight_as_3x3_f32(dw4, dw3, l.cout, l.cin, 1, ws));
       }
     }
   }
@@ -589,6 +606,7 @@ int backward(const Plan& P, const char* blob, const float* const* hp, const char
     else
       SR_TRY(sr_cb16_to_nchw_f32(gA, img(P.cin0, P.S), dx, n, P.cin0, P.S, P.S, 1, stream));
   }
+  lane.end();  // the caller's stream waits for the last weight gradient (the folded bf16 4x4 gradients are added below)
   if (nadd > 0) {
     if ((size_t)(small - W.small) > W.small_floats || nadd > kMaxAdd) {
       sr::set_error("sr_vgg_backward: internal scratch overflow (%d rows)", nadd);
@@ -709,3 +727,5 @@ extern "C" int sr_vgg_backward_bf16(const sr_vgg_cfg* cfg, const void* packed, c
   return backward_any(cfg, packed, host_params, saved, saved_bytes_, dlogits, n, train, host_dparams, accumulate, dx, workspace, workspace_bytes_,
                       true, stream);
 }
+
+extern "C" void sr_dev_set_vgg_lane(int on) { g_vgg_lane = on; }

@@ -42,6 +42,9 @@ if os.environ.get('FWD_GROUPS'):   # development: "<groups>,<min workgroups per 
     _l4.check(_l4.load().sr_set_forward_groups(int(_g[0])), 'sr_set_forward_groups')
     if len(_g) > 1:
         _l4.load().sr_dev_set_group_min_wgs(int(_g[1]))
+if os.environ.get('VGG_LANE'):   # development: 0 = the VGG discriminator's weight gradients on the caller's stream
+    from image_restoration_amd import _lib as _l6
+    _l6.load().sr_dev_set_vgg_lane(int(os.environ['VGG_LANE']))
 model = build_model(opt)
 lq = torch.from_numpy(synth.uniform_input(1, (B, 3, LQ, LQ))).cuda()
 gt = torch.from_numpy(synth.uniform_input(2, (B, 3, 4 * LQ, 4 * LQ))).cuda()
