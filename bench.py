@@ -240,6 +240,8 @@ def measure_train(world, rank, dev, dist, backend, *, yml, dtype, disc, disc_dty
         opt['network_d']['compute_dtype'] = d_dtype
     if os.environ.get('SR_BENCH_OVERLAP_G') == '0':   # tuning: G's optimiser step (and its weight gradients) before the critic phase
         opt['train']['overlap_g_wgrad'] = False
+    if os.environ.get('SR_BENCH_PREFETCH_D') == '0':   # tuning: net_d(gt) of the generator phase on the caller's stream
+        opt['train']['prefetch_d_real'] = False
     if os.environ.get('SR_BENCH_REUSE_D') == '0':   # tuning: every discriminator call of a step runs its own forward
         opt['train']['reuse_d_forwards'] = False
     set_random_seed(opt['manual_seed'] + rank)   # like parse_options: ranks start different, the model aligns its replicas

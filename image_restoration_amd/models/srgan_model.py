@@ -50,6 +50,9 @@ class SRGANModel(SRModel):
         # option key beyond the reference's (default on): run a repeated forward of a repeatable discriminator once per step
         self.reuse_d_forwards = bool(cfg.get('reuse_d_forwards', True))
         self._d_kept, self.d_forwards_run = {}, 0
+        # (same switch family) net_d(gt) of the generator phase on a second stream beside G's forward
+        self.prefetch_d_real = self.reuse_d_forwards and bool(cfg.get('prefetch_d_real', True)) and self.device.type == 'cuda'
+        self._d_side, self._d_real_ready = None, None
         # option key beyond the reference's (default on for a bf16 generator): G's weight gradients overlap the critic phase
         self.overlap_g_wgrad = bool(cfg.get('overlap_g_wgrad', True)) and getattr(self.net_g, 'compute_dtype', 'fp32') == 'bf16' \
             and self.device.type == 'cuda'
@@ -81,6 +84,28 @@ class SRGANModel(SRModel):
         self._d_kept[tag] = slot[0]
         return out
 
+    def _prefetch_real_logits(self, current_iter):
+        """``net_d(gt)`` of the generator phase (esrgan_model.py:38: no graph, constants for G) depends on nothing G computes, and
+        at the recipe's patch size neither it nor G's forward fills the chip: it is issued on a second stream BEFORE G's forward and
+        joined where its logits are used.  Only with a repeatable discriminator (the forward is kept and serves the critic phase,
+        its BatchNorm statistics land before the next call's by the event order) — same kernels, same order per buffer, same bits."""
+        self._d_real_ready = None
+        net = self.net_d
+        if not (self.prefetch_d_real and self.relativistic and self.generator_turn(current_iter) and net.training
+                and getattr(net, 'repeatable_forward', False) and self.gt.is_cuda):
+            return
+        cur = torch.cuda.current_stream()
+        if self._d_side is None:
+            self._d_side = torch.cuda.Stream()
+        side = self._d_side
+        side.wait_stream(cur)   # gt, D's weights (last step's Adam) and the refreshed buffers are final on the caller's stream
+        with torch.cuda.stream(side), torch.no_grad():
+            logits = self._critic(self.gt, 'gt')
+        kept = self._d_kept['gt']
+        for t in (kept.saved, kept.logits, logits):
+            t.record_stream(cur)   # allocated under the side stream, read by the caller's stream until the step ends
+        self._d_real_ready = (side.record_event(), logits)
+
     def generator_turn(self, current_iter):
         """G trains every ``net_d_iters`` iterations once ``net_d_init_iters`` have passed."""
         return current_iter > self.net_d_init_iters and current_iter % self.net_d_iters == 0
@@ -90,8 +115,13 @@ class SRGANModel(SRModel):
         """Generator-side GAN term on ``self.output`` (graph into G)."""
         if not self.relativistic:
             return self.cri_gan(self._critic(self.output, 'out'), True, is_disc=False)
-        with torch.no_grad():                      # esrgan_model.py:38 - real logits are constants for G
-            on_real = self._critic(self.gt, 'gt')
+        if self._d_real_ready is not None:         # issued beside G's forward (_prefetch_real_logits)
+            landed, on_real = self._d_real_ready
+            self._d_real_ready = None
+            torch.cuda.current_stream().wait_event(landed)
+        else:
+            with torch.no_grad():                  # esrgan_model.py:38 - real logits are constants for G
+                on_real = self._critic(self.gt, 'gt')
         on_fake = self._critic(self.output, 'out')
         gan = self.cri_gan.relativistic
         return (gan(on_real, on_fake, False, is_disc=False) + gan(on_fake, on_real, True, is_disc=False)) / 2
@@ -128,6 +158,7 @@ class SRGANModel(SRModel):
     def _generator_phase(self, book, current_iter):
         self.critic.freeze(True)
         self.gen.clear_grads()
+        self._prefetch_real_logits(current_iter)
         self.output = self.net_g(self.lq)
         if not self.generator_turn(current_iter):
             return
