@@ -676,7 +676,13 @@ extern "C" int sr_rrdbnet_backward_f32(const sr_rrdbnet_cfg* cfg, const float* p
         rc = sr::rdb_wgrad_f32(cat, D, cat_ns, n, h, w, cfg->num_feat, cfg->num_grow_ch, host_dparams + 2 * (1 + 5 * q), s5, accumulate,
                                B.slab, B.slab_bytes, ws);
         lane.done(ticket++);
-        if (rc) return rc;
+        if (rc < 0) return rc;
+        if (rc > 0) {  // widths whose tile-group sets do not fit one launch: conv by conv (D is complete, the order is free)
+          rc = wgrad(1 + 5 * q + 4, cat, cat_ns, h, w, 0, D, cat_ns, s5);
+          for (int sl = 4; sl >= 1 && !rc; --sl)
+            rc = wgrad(1 + 5 * q + (sl - 1), cat, cat_ns, h, w, 0, D + (long long)(P.nfp + (4 - sl) * P.gcp) * hw, cat_ns, 1.f);
+          if (rc) return rc;
+        }
       }
       // dL/dx = sum_k W_k[:, x]^T dY_k + sres * dL/d(out)  (+ dL/d(RRDB out) at the RRDB input, :63)
       lane.need(block_ticket[(gi + 1) & 3]);  // Dn was the D of the block three steps ago: its weight gradients have read it

@@ -540,10 +540,8 @@ int collect_group(const sr_conv3x3_wgrad_desc* d, WgradParams p, int cout_tile0,
                   const TapMap& tm) {
   RdbCollector& c = *g_collect;
   constexpr int P = CT * IT, KS = 4 / P, NT = KT * KT;
-  if (KT != 3 || R != 1 || c.m.nsub >= kMaxSub || !((CT == 2 && IT <= 2) || (CT == 1 && (IT == 4 || IT <= 2)))) {
-    sr::set_error("rdb_wgrad_f32: tile-group set <%d,%d,%d,%d> number %d is not collectable", CT, IT, R, KT, c.m.nsub);
-    return SR_EINVAL;
-  }
+  if (KT != 3 || R != 1 || c.m.nsub >= kMaxSub || !((CT == 2 && IT <= 2) || (CT == 1 && (IT == 4 || IT <= 2))))
+    return 1;  // (positive: not an error) more tile-group sets than one launch carries — the caller runs the convs one by one
   const int groups = grows * gi, i = c.m.nsub;
   p.cin_tile0 = cin_tile0;
   p.cout_tile0 = cout_tile0;
@@ -1008,6 +1006,8 @@ size_t rdb_wgrad_slab_bytes_f32(int n, int h, int w, int nf, int gc) {
 
 // The five weight gradients of one residual dense block (rrdbnet_arch.py:21-25) from its concat buffer `cat` = [x|x1..x4] and its
 // gradient concat buffer D = [dY5|dY4|dY3|dY2|dY1] (both CB8, image stride ns) as ONE launch + ONE table-driven reduction.
+// Returns 1 (nothing launched) when the block's widths need more than kMaxSub tile-group sets: the caller then issues
+// sr_conv3x3_wgrad_f32 per conv.
 // dparams[2k], [2k+1] = dweight / dbias of conv k+1 (null weight: skipped); conv5's gradient is scaled by scale5.  Per conv the
 // same products as sr_conv3x3_wgrad_f32; the sums run over fewer, longer row ranges (deterministic, another rounding order).
 int rdb_wgrad_f32(const float* cat, const float* D, long long ns, int n, int h, int w, int nf, int gc, float* const* dparams,
@@ -1017,7 +1017,7 @@ int rdb_wgrad_f32(const float* cat, const float* D, long long ns, int n, int h, 
     return SR_EINVAL;
   }
   RdbCollector whole;
-  if (int rc = rdb_collect(whole, cat, D, ns, n, h, w, nf, gc, dparams, scale5, accumulate)) return rc;
+  if (int rc = rdb_collect(whole, cat, D, ns, n, h, w, nf, gc, dparams, scale5, accumulate)) return rc;  // 1: does not fit one launch
   if (whole.m.nsub == 0) return SR_OK;  // every conv frozen
   RdbCollector c;
   c.rows = rdb_rows(whole, h);

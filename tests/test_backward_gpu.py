@@ -250,6 +250,7 @@ def test_weight_gradients_on_the_side_lane_equal_the_single_stream_backward_bit_
     (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=32, num_block=1, num_grow_ch=32), (2, 3, 20, 36)),   # C1's widths
     (dict(num_in_ch=1, num_out_ch=5, scale=2, num_feat=24, num_block=1, num_grow_ch=16), (1, 1, 18, 22)),   # padded channel counts
     (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=96, num_block=1, num_grow_ch=48), (2, 3, 16, 16)),   # three cout tiles in conv5
+    (dict(num_in_ch=3, num_out_ch=3, scale=4, num_feat=160, num_block=1, num_grow_ch=96), (1, 3, 8, 12)),   # more tile-group sets than one launch carries: conv by conv
 ])
 def test_dense_block_weight_gradients_in_one_launch_equal_the_per_conv_route(cuda, cfg, shape):
     """fp32 backward: the five weight gradients of a dense block go out as ONE launch + one table-driven reduction
