@@ -59,6 +59,11 @@ class VGGCfg(C.Structure):
     _fields_ = [('num_in_ch', C.c_int), ('num_feat', C.c_int), ('input_size', C.c_int)]
 
 
+class UNetCfg(C.Structure):
+    """struct sr_unet_cfg (include/sr_hip.h)."""
+    _fields_ = [('num_in_ch', C.c_int), ('num_feat', C.c_int), ('skip_connection', C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/sr_hip.h declares
 SIGNATURES = {
     'sr_version': (C.c_int, []),
@@ -255,6 +260,17 @@ for _suf, _plain in (('_f32', ''), ('_bf16', '_bf16')):
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                              C.c_void_p]),
     })
+SIGNATURES.update({
+    'sr_unet_num_params': (C.c_int, [C.POINTER(UNetCfg)]),
+    'sr_unet_packed_bytes_bf16': (C.c_size_t, [C.POINTER(UNetCfg)]),
+    'sr_unet_saved_bytes_bf16': (C.c_size_t, [C.POINTER(UNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_unet_workspace_bytes_bf16': (C.c_size_t, [C.POINTER(UNetCfg), C.c_int, C.c_int, C.c_int]),
+    'sr_unet_pack_bf16': (C.c_int, [C.POINTER(UNetCfg), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'sr_unet_forward_bf16': (C.c_int, [C.POINTER(UNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    'sr_unet_backward_bf16': (C.c_int, [C.POINTER(UNetCfg), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+})
 SIGNATURES.update({'sr_vgg_num_params': (C.c_int, [C.POINTER(VGGCfg)]), 'sr_vgg_num_batchnorm': (C.c_int, [C.POINTER(VGGCfg)])})
 
 _lib = None

@@ -85,7 +85,7 @@ class UNetDiscriminatorSN(nn.Module):
             raise _lib.SrHipError('UNetDiscriminatorSN.forward runs only on a HIP device (no CPU fallback)')
         assert x.size(2) % 8 == 0 and x.size(3) % 8 == 0, f'input {tuple(x.shape)} must be a multiple of 8 in H and W'
         if self.compute_dtype == 'bf16':
-            return self._forward_bf16(x)
+            return self._forward_driver_bf16(x) if self.use_driver else self._forward_bf16(x)
         sn = self._sn_weights()
         conv = A.ConvFn.apply
         x0 = conv(A.ToCB8.apply(x.contiguous().float()), self.conv0.weight, self.conv0.bias, 0.2)
@@ -108,6 +108,37 @@ class UNetDiscriminatorSN(nn.Module):
         out = conv(out, sn[8], None, 0.2)
         out = conv(out, self.conv9.weight, self.conv9.bias, 1.0)
         return A.FromCB8.apply(out, 1)
+
+    # ------------------------------------------------------------------ whole-network driver (bf16)
+    use_driver = True   # False: one autograd function per layer (_forward_bf16: the same launches; kept as the drivers' cross-check)
+
+    def _cfg(self):
+        return _lib.UNetCfg(self.num_in_ch, self.num_feat, int(bool(self.skip_connection)))
+
+    def _workspace(self, nbytes, dev):
+        ws = getattr(self, '_ws', None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws
+
+    def _forward_driver_bf16(self, x):
+        """archs/unet_disc_autograd.py: sr_unet_forward_bf16 / sr_unet_backward_bf16 behind ONE autograd function; the spectral
+        normalisation of conv1-8 stays the batched function in front of it.  Weights whose requires_grad flags differ (a partially
+        frozen network) take the per-layer route."""
+        if torch.is_grad_enabled() and len({p.requires_grad for p in self.parameters()}) > 1:
+            return self._forward_bf16(x)
+        sn = self._sn_weights()
+        weights = [self.conv0.weight, self.conv0.bias] + [sn[i] for i in range(1, 9)] + [self.conv9.weight, self.conv9.bias]
+        from .unet_disc_autograd import unet_apply
+        return unet_apply(self, x, weights)
+
+    def forward_layers(self, x):
+        """The same network one autograd function per layer (both precisions)."""
+        keep, self.use_driver = self.use_driver, False
+        try:
+            return self.forward(x)
+        finally:
+            self.use_driver = keep
 
     def _forward_bf16(self, x):
         """Same network on CB16 bf16 activations.  Neighbouring layers share memory passes (hip_autograd_bf16.py): the

@@ -585,6 +585,28 @@ int sr_vgg_backward_bf16(const sr_vgg_cfg* cfg, const void* packed, const float*
                          size_t saved_bytes, const float* dlogits, int n, int train, float* const* host_dparams, int accumulate,
                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------- whole U-Net discriminator (bf16) ---- */
+/* UNetDiscriminatorSN with compute_dtype = 'bf16' (the discriminator BASELINE configs 3-4 name; absent from the reference, SURVEY.md
+ * section 0 D2: the published architecture) as whole-network drivers like the VGG ones above: one call issues every launch of the forward /
+ * of autograd's backward with the descriptors of the per-layer host path, in its order — bit-identical to it.
+ * Spectral normalisation stays with the host: host_params are the EFFECTIVE weights of this forward, fp32 device tensors in the order
+ * conv0.weight, conv0.bias, conv1 .. conv8 (normalised weights, 4x4 for conv1-3, 3x3 for conv4-8), conv9.weight, conv9.bias (12);
+ * host_dparams receives the gradients wrt those (all NULL / host_dparams NULL: a frozen discriminator), written, not accumulated.
+ * One power iteration per train-mode forward changes the effective weights: `packed` and `saved` belong to ONE forward.
+ * x [n][num_in_ch][h][w] fp32 NCHW (h, w multiples of 8) -> logits [n][1][h][w] fp32; num_feat % 16 == 0. */
+typedef struct sr_unet_cfg {
+  int num_in_ch, num_feat, skip_connection;
+} sr_unet_cfg;
+int sr_unet_num_params(const sr_unet_cfg* cfg);
+size_t sr_unet_packed_bytes_bf16(const sr_unet_cfg* cfg);
+size_t sr_unet_saved_bytes_bf16(const sr_unet_cfg* cfg, int n, int h, int w);
+size_t sr_unet_workspace_bytes_bf16(const sr_unet_cfg* cfg, int n, int h, int w);
+int sr_unet_pack_bf16(const sr_unet_cfg* cfg, const float* const* host_params, void* packed, void* stream);
+int sr_unet_forward_bf16(const sr_unet_cfg* cfg, const void* packed, const float* x, float* logits, int n, int h, int w, void* saved,
+                         size_t saved_bytes, void* stream);
+int sr_unet_backward_bf16(const sr_unet_cfg* cfg, const void* packed, const void* saved, size_t saved_bytes, const float* dlogits, int n,
+                          int h, int w, float* const* host_dparams, float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradients of the generator under the discriminator phase (bf16 backward).  The generator's weight gradients feed only its
  * optimiser step, and the discriminator phase of an ESRGAN step (esrgan_model.py:51-73) reads self.output and D's weights only, so
  * nothing between G's backward and G's optimiser step needs them.  With sr_set_backward_wgrad_deferred(1), sr_rrdbnet_backward_bf16
