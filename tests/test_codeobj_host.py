@@ -56,8 +56,10 @@ def _kernels(code_objects, needle):
     return {n: (path, md) for path, ks in code_objects for n, md in ks.items() if needle in n}
 
 
+# (round 4: wgrad_f32_rdb_kernel switches between five instances of the fp32 weight-gradient body — 144 accumulator registers each —
+# inside one kernel: a spill there would put scratch traffic into every dense block's backward)
 @pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('rdb_fused8_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4), ('wgrad_bf16_kernel', 10),
-                                             ('wgrad_rdb_bf16_kernel', 2)])
+                                             ('wgrad_rdb_bf16_kernel', 2), ('wgrad_f32_rdb_kernel', 1), ('wgrad_f32_kernel', 5)])
 def test_one_workgroup_per_cu_kernels_have_no_scratch_and_no_spills(code_objects, needle, at_least):
     ks = _kernels(code_objects, needle)
     assert len(ks) >= at_least, sorted(ks)
