@@ -397,19 +397,22 @@ struct ReduceParams {
   int accumulate;
 };
 
-// One thread per (pair, 8-cout group g, lane): its four couts x all taps.  Reads are float4 (the four couts of a lane sit side by
-// side in the partial tiles), and the taps of one (cout, cin) are consecutive floats of the OIHW gradient, so a wave's lanes
-// (consecutive cin positions) write runs of 32 x ntap floats per cout instead of single floats 36 bytes apart (round 4: the
-// one-element-per-thread form cost 34 us per dense block in the fp32 recipe).  Per element the same sum in the same order.
 __device__ __forceinline__ void wgrad_reduce2_body(const ReduceParams& p, int grp) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // One thread per element (coalesced partial reads, many independent threads).  A form with one thread per (cout quad, cin position)
+  // and a tap loop — float4 reads, 36-byte runs of the OIHW gradient per thread — was measured slower (round 4: 8.8 -> 27.9 us per
+  // single-set launch, 34.5 -> 44.5 us per dense-block table): P x 256 threads with 9 x sch dependent loads each are latency-bound.
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_split = p.P * p.ntap * 1024;
   const int grow = grp / p.gi, gcol = grp - grow * p.gi;
   const int cout_tile0 = p.cout_tile0 + grow * p.CT, cin_tile0 = p.cin_tile0 + gcol * p.IT;
-  if (t < p.P * 256) {
-    const int lane = t & 63, g = (t >> 6) & 3, pair = t >> 8;
+  if (idx < per_split) {
+    float s = 0.f;
+    const float* part = p.part + (long long)grp * p.sch * per_split;
+    for (int k = 0; k < p.sch; ++k) s += part[(long long)k * per_split + idx];
+    const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 3;
+    const int tap = (idx >> 10) % p.ntap, pair = idx / (p.ntap * 1024);
     const int ct = pair / p.IT, it = pair % p.IT;
-    const int co0 = (cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5);
+    const int co = (cout_tile0 + ct) * 32 + 8 * g + 4 * (lane >> 5) + e;
     const int pos = (cin_tile0 + it) * 32 + (lane & 31);
     // invert the concat position map of sr_conv3x3_pack_f32
     int ci = -1;
@@ -421,42 +424,17 @@ __device__ __forceinline__ void wgrad_reduce2_body(const ReduceParams& p, int gr
       const int r = pos - fsp, sgi = r / sp, o = r % sp;
       if (o < p.seg) ci = p.first_seg + sgi * p.seg + o;
     }
-    if (ci >= 0 && ci < p.cin && co0 < p.cout) {
-      const float* part = p.part + (long long)grp * p.sch * per_split + ((long long)pair * p.ntap * 4 + g) * 256 + lane * 4;
-      for (int tap = 0; tap < p.ntap; ++tap) {
-        const float* q = part + tap * 1024;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= p.sch; k += 4) {  // four loads in flight; the adds stay in split order
-          const float4 a = *(const float4*)(q + (long long)k * per_split), b = *(const float4*)(q + (long long)(k + 1) * per_split);
-          const float4 c = *(const float4*)(q + (long long)(k + 2) * per_split), d = *(const float4*)(q + (long long)(k + 3) * per_split);
-          s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
-          s0 += b.x; s1 += b.y; s2 += b.z; s3 += b.w;
-          s0 += c.x; s1 += c.y; s2 += c.z; s3 += c.w;
-          s0 += d.x; s1 += d.y; s2 += d.z; s3 += d.w;
-        }
-        for (; k < p.sch; ++k) {
-          const float4 a = *(const float4*)(q + (long long)k * per_split);
-          s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
-        }
-        const int ky = (tap / p.ks) * p.t_mul + p.dy_off, kx = (tap % p.ks) * p.t_mul + p.dx_off;
-        const float sv[4] = {s0, s1, s2, s3};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int co = co0 + e;
-          if (co < p.cout) {
-            float* o = p.dw + (((long long)co * p.cin + ci) * p.kdim + ky) * p.kdim + kx;
-            *o = p.accumulate ? *o + sv[e] * p.scale : sv[e] * p.scale;
-          }
-        }
-      }
+    if (co < p.cout && ci >= 0 && ci < p.cin) {
+      const int ky = (tap / p.ks) * p.t_mul + p.dy_off, kx = (tap % p.ks) * p.t_mul + p.dx_off;
+      float* o = p.dw + (((long long)co * p.cin + ci) * p.kdim + ky) * p.kdim + kx;
+      *o = p.accumulate ? *o + s * p.scale : s * p.scale;
     }
   }
-  if (p.db && p.bpart && gcol == 0 && t < p.CT * 32) {
+  if (p.db && p.bpart && gcol == 0 && idx < p.CT * 32) {
     float s = 0.f;
     const float* bpart = p.bpart + (long long)grow * p.sch * p.CT * 32;
-    for (int k = 0; k < p.sch; ++k) s += bpart[k * p.CT * 32 + t];
-    const int co = cout_tile0 * 32 + t;
+    for (int k = 0; k < p.sch; ++k) s += bpart[k * p.CT * 32 + idx];
+    const int co = cout_tile0 * 32 + idx;
     if (co < p.cout) p.db[co] = p.accumulate ? p.db[co] + s * p.scale : s * p.scale;
   }
 }
@@ -742,7 +720,7 @@ int wgrad_reduce(const WgradReduce& r, hipStream_t stream) {
                      r.split_stride ? r.split_stride / 4 : (long long)e4, r.bsplit_stride ? r.bsplit_stride : r.CT * 32, gi);
   SR_CHECK_LAUNCH("wgrad_reduce1 launch");
   const ReduceParams rp = reduce2_params(r, sch, gi);
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(r.P, groups), dim3(256), 0, stream, rp);  // 256 (g, lane) threads per pair
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((r.P * r.ntap * 1024 + 255) / 256, groups), dim3(256), 0, stream, rp);
   SR_CHECK_LAUNCH("wgrad_reduce2 launch");
   return SR_OK;
 }
@@ -763,7 +741,7 @@ int wgrad_reduce_rows(const WgradReduce* r, int nrows, hipStream_t stream) {
     }
     sum_p += r[i].P * r[i].ntap;
     max_e4 = std::max(max_e4, r[i].P * r[i].ntap * 256);
-    max_e = std::max(max_e, r[i].P * 256);  // stage 2: one thread per (pair, cout group, lane)
+    max_e = std::max(max_e, r[i].P * r[i].ntap * 1024);
   }
   int sch = (int)((r[0].splits + 15) / 16);  // (16 splits per stage-1 block: the dense block's 64-split launches were ONE chunk of eight dependent rounds of loads)
   int cap = (int)((size_t)64 * 4 * 9 / (size_t)sum_p);  // part holds 64 * 4*9*1024 floats, bpart 64*64
@@ -1075,7 +1053,7 @@ int rdb_wgrad_f32(const float* cat, const float* D, long long ns, int n, int h, 
     t2.z0[i] = c.m.y0[i];
     max_cols = std::max(max_cols, (a.e4 + 255) / 256 + 1);
     max_sch = std::max(max_sch, a.sch);
-    max_e = std::max(max_e, q.P * 256);  // stage 2: one thread per (pair, cout group, lane)
+    max_e = std::max(max_e, q.P * q.ntap * 1024);
   }
   t1.nrows = t2.nrows = c.m.nsub;
   t2.z0[c.m.nsub] = c.total_groups;
