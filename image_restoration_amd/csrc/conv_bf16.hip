@@ -859,6 +859,26 @@ __global__ __launch_bounds__(512, TALL ? 2 : 4) void conv_chain_bf16_kernel(cons
 #undef SR_FZ_NS
 #undef SR_FZ_PT
 #undef SR_FZ_KERNEL
+// ... and the 16-row tile on FOUR waves of four rows each (one wave per SIMD, 512 registers): a weight fragment read from the LDS
+// feeds four MFMAs instead of two and six pixel rows serve four output rows instead of four serving two — 0.44 of the LDS read bytes
+// per tile.  The chip holds this kernel's clock down under load (1.5 GHz; in cycles the tile is 1.4 x its MFMAs), and LDS
+// read bytes are what the clock pays for.  Schedule, ring and lags of the 16-row instance.
+#define SR_FZ_NS fz4
+#define SR_FZ_PT 4
+#undef SR_FZ_NW
+#define SR_FZ_NW 4
+#define SR_FZ_KERNEL rdb_fused4_bf16_kernel
+#undef SR_FZ_RING
+#undef SR_FZ_PERDX
+#undef SR_FZ_CLAIMLEAD
+#undef SR_FZ_PUBLAG
+#undef SR_FZ_TILELAG
+#undef SR_FZ_FLAGLEAD
+#include "fused_block.inc"
+#undef SR_FZ_NS
+#undef SR_FZ_PT
+#undef SR_FZ_NW
+#undef SR_FZ_KERNEL
 
 // ------------------------------------------------------------------------------------------------ streaming conv (Cin <= 64)
 // The large-image layers with few input channels — conv_hr / the upsampling convs of the generator's head, the U-Net
@@ -1300,6 +1320,8 @@ extern "C" size_t sr_conv3x3_chain_sync_ints(int n, int h, int w) {
 // reference recipe's step 21.2 -> 20.0 ms.  2 = also the transposed block of the backward pass: 21.9 ms — that block shares the chip
 // with the weight-gradient lane, which loses more CUs to 128 small tiles than the block gains.  (sr_dev_set_fused_rows8)
 static int g_fused_rows8 = 1;
+// the lean 16-row launches on four waves of four rows (rdb_fused4_bf16_kernel) instead of eight of two.  (sr_dev_set_fused_wave4)
+static int g_fused_wave4 = 0;
 static int g_chain_enabled = 3;  // 0 off, 1 = 32-row ring tiles (one workgroup per CU), 2 = 16-row tiles (two workgroups per CU),
                                  // 3 = fused dense block (rdb_fused_bf16_kernel) where eligible, else as 2
 static long long* g_chain_clocks = nullptr;
@@ -1461,6 +1483,20 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
       hipLaunchKernelGGL(rdb_fused8_bf16_kernel<2>, dim3((unsigned)grid), dim3(512), fz8::LDS_BYTES, stream, P8);
     else
       hipLaunchKernelGGL(rdb_fused8_bf16_kernel<0>, dim3((unsigned)grid), dim3(512), fz8::LDS_BYTES, stream, P8);
+  } else if (g_fused_wave4 && (lean || back)) {
+    static_assert(sizeof(fz4::FusedParams) == sizeof(fz::FusedParams), "one parameter block for every instance");
+    static bool lds4[16] = {false};
+    if (!lds4[dev]) {
+      if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused4_bf16_kernel<1>, fz4::LDS_BYTES)) return rc;
+      if (int rc = sr::ensure_dynamic_lds((const void*)rdb_fused4_bf16_kernel<2>, fz4::LDS_BYTES)) return rc;
+      lds4[dev] = true;
+    }
+    fz4::FusedParams P4;
+    std::memcpy(&P4, &P, sizeof(P));
+    if (lean)
+      hipLaunchKernelGGL(rdb_fused4_bf16_kernel<1>, dim3((unsigned)grid), dim3(fz4::NW * 64), fz4::LDS_BYTES, stream, P4);
+    else
+      hipLaunchKernelGGL(rdb_fused4_bf16_kernel<2>, dim3((unsigned)grid), dim3(fz4::NW * 64), fz4::LDS_BYTES, stream, P4);
   } else if (lean)
     hipLaunchKernelGGL(rdb_fused_bf16_kernel<1>, dim3((unsigned)grid), dim3(512), fz::LDS_BYTES, stream, P);
   else if (back)
@@ -1474,6 +1510,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
 }
 
 extern "C" void sr_dev_set_fused_rows8(int on) { g_fused_rows8 = on; }
+extern "C" void sr_dev_set_fused_wave4(int on) { g_fused_wave4 = on; }
 
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

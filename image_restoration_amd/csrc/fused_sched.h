@@ -8,8 +8,19 @@
 #ifndef SR_FZ_PT
 #define SR_FZ_PT 2
 #endif
+#ifndef SR_FZ_NW
+#define SR_FZ_NW 8  // waves of a workgroup (each owns SR_FZ_PT tile rows): 8 = two per SIMD, 256 registers each; 4 = one per SIMD, 512
+#endif
 namespace SR_FZ_NS {
-constexpr int NW = 8, PT = SR_FZ_PT, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
+constexpr int NW = SR_FZ_NW, GPW = 8 / NW;  // GPW: LDS-DMA instructions of one wave per weight group (a group = eight 1 KB pieces)
+static_assert(NW * GPW == 8, "a weight group is dealt out evenly");
+#ifndef SR_FZ_SLICED
+#define SR_FZ_SLICED (SR_FZ_NW == 4)
+#endif
+// one wave per SIMD: nobody else's MFMAs cover a wave's address arithmetic, so what a step issues to memory is dealt out over the gaps
+// behind ALL of its MFMAs (same order: the counted waits do not change)
+constexpr bool kSliced = SR_FZ_SLICED;
+constexpr int PT = SR_FZ_PT, TH = NW * PT, XROW = 34, XPIX = (TH + 2) * XROW;
 constexpr int XU = (XPIX * 32 + 1023) / 1024, XBUF = XU * 1024, NTB = 6;  // 1 KiB pieces / bytes of a tile buffer ((TH + 2) x 34 pixels x 32 B, rounded up: 20 / 11)
 constexpr int TPW = (2 * XU + NW - 1) / NW;  // pieces of a tile pair (two chunks) per wave: 5 (exactly 40 pieces) / 3 (22 pieces + 2 into a spare KB)
 constexpr bool kTileSurplus = TPW * NW > 2 * XU;
@@ -95,7 +106,8 @@ constexpr int in_chunks(int s) { return s == 0 ? 4 : 2; }
 constexpr int in_cb0(int s) { return s == 0 ? 0 : 4 + 2 * (s - 1); }
 constexpr int in_tb0(int s) { return s == 0 ? 0 : s == 1 ? 4 : s == 2 ? 0 : s == 3 ? 2 : 4; }
 
-constexpr int kMaskLead[4] = {1, 0, 1, 1};  // conv2 completes while 160 accumulator registers are live: its mask is fetched last-minute
+// conv2 completes while 160 of 256 registers are accumulators: its mask is fetched last-minute (the four-wave instance has room: a step ahead)
+constexpr int kMaskLead[4] = {1, NW == 4 ? 1 : 0, 1, 1};
 constexpr int mask_conv_at(const Sched& s, const int i) {  // the conv (1..4) whose mask is fetched at step i, or 0
   for (int k = 1; k <= 4; ++k) {
     const int j = i + kMaskLead[k - 1];
@@ -228,7 +240,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
   tend[0][1] = seq;
   int issued = RING / 8;  // whole groups that fit the empty ring
   s.q_init = issued;
-  for (int q = 0; q < issued; ++q) gend[q] = ++seq;
+  for (int q = 0; q < issued; ++q) gend[q] = seq += GPW;
   for (int i = 0; i < ns; ++i) {
     StepD& d = s.st[i];
     // the barrier of step i says: step i's operands have landed, and so have those that step i reads ahead for step i+1 — its tile and
@@ -257,10 +269,10 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     if (q1 > s.ngroups) q1 = s.ngroups;
     d.q0 = issued;
     d.q1 = q1;
-    for (int q = issued; q < q1; ++q) gend[q] = ++seq;
+    for (int q = issued; q < q1; ++q) gend[q] = seq += GPW;
     issued = q1;
     if (d.nx_tile) seq += TPW;
-    seq += d.nx_q1 - d.nx_q0;
+    seq += (d.nx_q1 - d.nx_q0) * GPW;
     if (mode && d.first_of_in == 4) seq += 8 * PT;  // lean kernels: conv5's residual sources are fetched here (2 sources x 2 cout tiles x PT rows x 2 blocks)
     if (mode == 2 && mask_conv_at(s, i)) seq += 2 * PT;  // ... and conv k's mask kMaskLead steps before its epilogue
     if (d.claim == 1) cseq = seq;  // thread 0 only: the ticket atomic, behind everything this step issues
@@ -269,7 +281,10 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
       seq += 2 * PT;  // the epilogue's stores: PT rows x 2 channel blocks
       send[d.post] = seq;
     }
-    if (d.K > 60 || d.Kflag > 60 || d.Kclaim > 60) s.ok = 0;
+    // (the counter has six bits; a smaller number only waits for more)
+    if (d.K > 60) d.K = 60;
+    if (d.Kflag > 60) d.Kflag = 60;
+    if (d.Kclaim > 60) d.Kclaim = 60;
   }
   if (issued != s.ngroups) s.ok = 0;
   return s;

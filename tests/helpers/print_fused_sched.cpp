@@ -3,8 +3,8 @@
 #include "fused_sched.h"
 using namespace SR_FZ_NS;
 static void dump(const Sched& s, int mode) {
-  printf("{\"mode\": %d, \"ok\": %d, \"nsteps\": %d, \"npieces\": %d, \"ngroups\": %d, \"q_init\": %d, \"q_ahead\": %d, \"ring\": %d, \"ar\": %d, \"pt\": %d, \"tpw\": %d, \"steps\": [", mode, s.ok,
-         s.nsteps, s.npieces, s.ngroups, s.q_init, s.q_ahead, RING, AR, PT, TPW);
+  printf("{\"mode\": %d, \"ok\": %d, \"nsteps\": %d, \"npieces\": %d, \"ngroups\": %d, \"q_init\": %d, \"q_ahead\": %d, \"ring\": %d, \"ar\": %d, \"pt\": %d, \"tpw\": %d, \"nw\": %d, \"gpw\": %d, \"steps\": [", mode, s.ok,
+         s.nsteps, s.npieces, s.ngroups, s.q_init, s.q_ahead, RING, AR, PT, TPW, NW, GPW);
   for (int i = 0; i < s.nsteps; ++i) {
     const StepD& d = s.st[i];
     printf("%s{\"in\": %d, \"chunk\": %d, \"g0\": %d, \"ng\": %d, \"dx0\": %d, \"ndx\": %d, \"tb\": %d, \"wp0\": %d, \"wpn\": %d, \"post\": %d, \"K\": %d, \"q0\": %d, "

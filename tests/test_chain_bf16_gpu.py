@@ -15,12 +15,27 @@ from image_restoration_amd import hip_ops as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def chain_restore():
+WAVE4_DEFAULT = 0   # the library's default for sr_dev_set_fused_wave4 (csrc/conv_bf16.hip: g_fused_wave4)
+
+
+@pytest.fixture(autouse=True, params=['waves8', 'waves4'])
+def chain_restore(request):
     """Both tile geometries of the chain launch (sr_set_conv_chain 1: 32-row ring tiles, 2: 16-row tiles) and the fused kernel (3, the
-    library's default, restored afterwards so that the tests that follow in the same process run what the product runs)."""
+    library's default, restored afterwards so that the tests that follow in the same process run what the product runs).  Every test
+    that reaches the fused kernel runs twice: its 16-row tiles on eight waves of two rows and on four waves of four rows
+    (rdb_fused4_bf16_kernel, `sr_dev_set_fused_wave4`)."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.sr_dev_set_fused_wave4.argtypes = [C.c_int]
+    lib.sr_dev_set_fused_wave4.restype = None
+    w4 = request.param == 'waves4'
+    callspec = getattr(request.node, 'callspec', None)
+    if w4 and callspec is not None and callspec.params.get('mode', 3) != 3:
+        pytest.skip('the four-wave instance is a variant of the fused kernel (mode 3) only')
+    lib.sr_dev_set_fused_wave4(1 if w4 else 0)
     yield
-    _lib.check(_lib.load().sr_set_conv_chain(3), 'sr_set_conv_chain')
+    lib.sr_dev_set_fused_wave4(WAVE4_DEFAULT)
+    _lib.check(lib.sr_set_conv_chain(3), 'sr_set_conv_chain')
 
 
 def _rdb(dev, nf, gc, seed):

@@ -58,15 +58,16 @@ def _kernels(code_objects, needle):
 
 # (round 4: wgrad_f32_rdb_kernel switches between five instances of the fp32 weight-gradient body — 144 accumulator registers each —
 # inside one kernel: a spill there would put scratch traffic into every dense block's backward)
-@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('rdb_fused8_bf16_kernel', 3), ('conv_stream_bf16_kernel', 4), ('wgrad_bf16_kernel', 10),
-                                             ('wgrad_rdb_bf16_kernel', 2), ('wgrad_f32_rdb_kernel', 1), ('wgrad_f32_kernel', 5)])
+# (rdb_fused4_bf16_kernel: the 16-row tile on four waves, one per SIMD — 512 registers per lane, accumulators in the AGPR half)
+@pytest.mark.parametrize('needle,at_least', [('rdb_fused_bf16_kernel', 3), ('rdb_fused8_bf16_kernel', 3), ('rdb_fused4_bf16_kernel', 2), ('conv_stream_bf16_kernel', 4),
+                                             ('wgrad_bf16_kernel', 10), ('wgrad_rdb_bf16_kernel', 2), ('wgrad_f32_rdb_kernel', 1), ('wgrad_f32_kernel', 5)])
 def test_one_workgroup_per_cu_kernels_have_no_scratch_and_no_spills(code_objects, needle, at_least):
     ks = _kernels(code_objects, needle)
     assert len(ks) >= at_least, sorted(ks)
     for name, (_, md) in ks.items():
         assert md['private_segment_fixed_size'] == 0, (name, md)
         assert md['vgpr_spill_count'] == 0, (name, md)   # (SGPR spills go to VGPR lanes, not to memory: not a concern here)
-        assert md['vgpr_count'] <= 256, (name, md)
+        assert md['vgpr_count'] <= (512 if 'rdb_fused4' in name else 256), (name, md)
 
 
 def _regs(operands):
@@ -78,10 +79,10 @@ def _regs(operands):
     return regs
 
 
-@pytest.mark.parametrize('needle', ['rdb_fused_bf16_kernel', 'rdb_fused8_bf16_kernel'])   # the 16-row and the 8-row instance
-def test_fused_kernel_ticket_register_is_untouched_until_its_counted_wait(code_objects, needle):
+@pytest.mark.parametrize('needle,instances', [('rdb_fused_bf16_kernel', 3), ('rdb_fused8_bf16_kernel', 3), ('rdb_fused4_bf16_kernel', 2)])   # 16-row, 8-row, 16-row on four waves
+def test_fused_kernel_ticket_register_is_untouched_until_its_counted_wait(code_objects, needle, instances):
     ks = _kernels(code_objects, needle)
-    assert len(ks) == 3
+    assert len(ks) == instances
     path = next(iter(ks.values()))[0]
     dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', path], check=True, capture_output=True,
                          text=True).stdout.splitlines()
@@ -106,4 +107,38 @@ def test_fused_kernel_ticket_register_is_untouched_until_its_counted_wait(code_o
                     break
             else:
                 pytest.fail(f'{name}: the ticket in v{dst} is never consumed')
-    assert checked == 6
+    assert checked == 2 * instances
+
+
+# (the 16-row instances: their schedules have no step whose counted wait is 0; the 8-row instance's short lags do)
+@pytest.mark.parametrize('needle,instances', [('rdb_fused_bf16_kernel', 3), ('rdb_fused4_bf16_kernel', 2)])
+def test_fused_kernel_never_drains_its_memory_queue_inside_a_tile(code_objects, needle, instances):
+    """Every wait of the step stream is a COUNTED one (fused_sched.h).  Round 4 found an ``s_waitcnt vmcnt(0)`` that hipcc had put behind
+    the barrier of each of the four steps that inspect neighbour flags (a compiler-visible store / load in the stamp and slow-poll code
+    whose registers were reused right after): a full drain of the LDS-DMA read-ahead, for every wave, stamps on or off.  Those
+    accesses are inline asm now; what may remain are the drains of the slow path itself (directly behind its agent-scope load / store),
+    of the kernel's prologue (before the first MFMA) and the one at the kernel's end.  The lean instances (forward and transposed block);
+    the generic-epilogue instance <0> loads bias / residual / mask values inside its epilogues and waits for them."""
+    ks = _kernels(code_objects, needle)
+    assert len(ks) == instances
+    path = next(iter(ks.values()))[0]
+    dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', path], check=True, capture_output=True,
+                         text=True).stdout.splitlines()
+    lean = [n for n in ks if 'ILi0E' not in n]
+    assert len(lean) == 2
+    for name in lean:
+        start = next(i for i, l in enumerate(dis) if l.rstrip().endswith(f'<{name}>:'))
+        end = next((i for i in range(start + 1, len(dis)) if re.match(r'^[0-9a-f]+ <', dis[i])), len(dis))
+        body = [l.split('//')[0].strip() for l in dis[start + 1:end]]
+        body = [l for l in body if l]
+        first_mfma = min(i for i, l in enumerate(body) if l.startswith('v_mfma'))
+        last_mfma = max(i for i, l in enumerate(body) if l.startswith('v_mfma'))
+        stray = []
+        for i, l in enumerate(body):
+            if l.startswith('s_waitcnt') and 'vmcnt(0)' in l and first_mfma < i < last_mfma:
+                prev = body[i - 1]
+                if not ((prev.startswith('global_load_dword ') or prev.startswith('global_store_dword ')) and 'sc1' in prev):
+                    stray.append((i, prev, l))
+        # (the eight-wave transposed block fetches conv2's mask in the step that needs it — no register to hold it longer — and waits)
+        allowed = 1 if needle == 'rdb_fused_bf16_kernel' and 'ILi2E' in name else 0
+        assert len(stray) == allowed, (name, stray[:4])

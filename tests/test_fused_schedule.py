@@ -21,10 +21,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, '..', 'image_restoration_amd', 'csrc')
 
 
-# the two instances conv_bf16.hip builds: 16-row tiles (the header's defaults) and 8-row tiles with a chunk per step (the macros
-# conv_bf16.hip sets in front of its second inclusion of fused_block.inc)
+# the three instances conv_bf16.hip builds: 16-row tiles (the header's defaults), 8-row tiles with a chunk per step, and the 16-row
+# tile on four waves of four rows (the macros conv_bf16.hip sets in front of its second / third inclusion of fused_block.inc)
 INSTANCES = {
     'rows16': [],
+    'rows16_waves4': ['-DSR_FZ_NW=4', '-DSR_FZ_PT=4'],
     'rows8': ['-DSR_FZ_PT=1', '-DSR_FZ_RING=64', '-DSR_FZ_PERDX=0', '-DSR_FZ_CLAIMLEAD=2', '-DSR_FZ_PUBLAG={1,1,1,1}', '-DSR_FZ_TILELAG={2,2,2,2}',
               '-DSR_FZ_FLAGLEAD={1,1,1,1}'],
 }
@@ -50,7 +51,9 @@ def replay(s, following):
     ops = []
 
     def issue(kind, payload, step):
-        for _ in range(s['tpw'] if kind in ('tile', 'nxtile') else 1):   # two tile chunks = 2 XU pieces of 1 KB, TPW per wave (40 = five each on 16-row tiles)
+        # two tile chunks = 2 XU pieces of 1 KB, TPW per wave (40 = five each on 16-row tiles with eight waves); a weight group = eight
+        # pieces, GPW per wave
+        for _ in range(s['tpw'] if kind in ('tile', 'nxtile') else s['gpw'] if kind in ('w', 'nxw') else 1):
             ops.append((kind, payload, step))
         return len(ops)          # position: number of ops issued up to and including this one
 

@@ -20,9 +20,12 @@ for _t in range(1, 5):
 NAMES.update({40: 'conv5 last step', 41: 'conv5 epilogue', 42: 'end'})
 
 
-def run(n, h, w, nf=64, gc=32):
+def run(n, h, w, nf=64, gc=32, wave4=0):
     lib = _lib.load()
     lib.sr_dev_fused_phase_clocks.argtypes = [C.c_void_p]
+    lib.sr_dev_set_fused_wave4.argtypes = [C.c_int]
+    lib.sr_dev_set_fused_wave4(wave4)
+    print('four waves of four rows' if wave4 else 'eight waves of two rows')
     lib.sr_set_conv_chain(3)
     dev = torch.device('cuda')
     packs = _rdb(dev, nf, gc, 3)
@@ -56,5 +59,5 @@ def run(n, h, w, nf=64, gc=32):
 
 
 if __name__ == '__main__':
-    run(8, 128, 128)
     run(16, 128, 128)
+    run(16, 128, 128, wave4=1)
