@@ -1347,7 +1347,9 @@ extern "C" void sr_dev_fused_grid_cap(int cap) { g_fused_grid_cap = cap; }
 
 // The dense block as rdb_fused_bf16_kernel when the five descriptors are one (64 + 4 x 32 channel) block over a single concat buffer and
 // every image's tiles fit the chip together; *launched says whether it ran.
-static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int call_index, hipStream_t stream, bool* launched) {
+static int g_mids_scratch = 0;  // development / tests: every forward dense block as if its caller had said "x1..x4 are scratch"
+extern "C" void sr_dev_set_chain_mids_scratch(int on) { g_mids_scratch = on; }
+static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int call_index, hipStream_t stream, bool* launched, bool mids_scratch) {
   *launched = false;
   const int n = d[0].n, h = d[0].in_h, w = d[0].in_w;
   const long long hw = (long long)h * w;
@@ -1457,6 +1459,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     for (int k = 0; k < 4; ++k) P.mask[k] = P.lv[k].mask;
     P.mask_nb = P.lv[0].mask_nb;
     P.mask_slope = d[0].mask_slope;
+    P.mids_scratch = (lean && (mids_scratch || g_mids_scratch)) ? 1 : 0;
   }
   const bool prof = sr::prof_on();
   if (prof) {  // one record for the whole block: the FLOPs of its five convs, the bytes a block must move at least
@@ -1513,11 +1516,15 @@ extern "C" void sr_dev_set_fused_rows8(int on) { g_fused_rows8 = on; }
 extern "C" void sr_dev_set_fused_wave4(int on) { g_fused_wave4 = on; }
 
 extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return sr::conv3x3_chain_bf16(d, nconv, sync, call_index, (hipStream_t)stream_, false);
+}
+// mids_scratch: the caller reads nothing but the LAST conv's output afterwards (the inference forward: the concat buffer behind a
+// dense block is scratch) — the fused kernel then stores of x1..x4 only what neighbouring tiles read; every other path stores all
+int sr::conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, hipStream_t stream, bool mids_scratch) {
   SR_CHECK_ARG(d && nconv >= 1, "sr_conv3x3_chain_bf16: bad argument");
   if (g_chain_enabled >= 3 && sync && nconv == 5 && call_index >= 0 && call_index < SR_CHAIN_EPOCHS) {  // (also when profiling: one record)
     bool launched = false;
-    if (int rc = try_fused_dense_block(d, sync, call_index, stream, &launched)) return rc;
+    if (int rc = try_fused_dense_block(d, sync, call_index, stream, &launched, mids_scratch)) return rc;
     if (launched) return SR_OK;
   }
   // eligibility of the one-launch form: one tile grid (same n, H, W, no upsampling), CB16 outputs, <= 64 couts, 16-row tiles,
@@ -1535,7 +1542,7 @@ extern "C" int sr_conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_
   if (one_launch) one_launch = (long long)sr::cdiv(d[0].in_w, 32) * (d[0].in_h / rows) * d[0].n * conc >= (tall ? 192 : 384);
   if (!one_launch) {
     for (int k = 0; k < nconv; ++k)
-      if (int rc = sr_conv3x3_bf16(&d[k], stream_)) return rc;
+      if (int rc = sr_conv3x3_bf16(&d[k], (void*)stream)) return rc;
     return SR_OK;
   }
   ChainParams P = {};

@@ -34,8 +34,23 @@ constexpr int LDS_FLAGS = LDS_X0 + NTB * XBUF;      // 64 words: neighbour progr
 constexpr int LDS_BIAS = LDS_FLAGS + 256;           // 5 x 64 floats
 constexpr int LDS_WTAB = LDS_BIAS + 5 * 64 * 4;     // source offset of every weight piece (480 words)
 constexpr int LDS_SPARE = LDS_WTAB + 480 * 4;       // 1 KB for the surplus pieces of a tile pair (8-row tiles only)
-constexpr int LDS_BYTES = LDS_SPARE + (kTileSurplus ? 1024 : 0);
+// Lean instances (SR_FZ_HALO): a conv's tile goes from the accumulators straight into the LDS buffer of the input it becomes (its
+// producer is the workgroup that reads it); only the one-pixel ring around it comes from the neighbours through memory — the tile's
+// first / last two 1 KB pieces in place (rows 0 and TH + 1 and what shares their pieces: re-fetched pixels of the workgroup's own,
+// already published, border rows) and the two halo COLUMNS through 1 KB of staging per chunk (a DMA's LDS destination is contiguous;
+// a wave copies them to their places a step before the first use).  HPW in-place pieces per wave; waves 0 / 1 add the staging piece
+// of chunk 0 / 1 right behind theirs (the counted waits are those of a wave without it: a wave with one more operation in flight
+// only waits longer).
+#ifndef SR_FZ_HALO
+#define SR_FZ_HALO 1
+#endif
+constexpr bool kHalo = SR_FZ_HALO;
+constexpr int HPW = 8 / NW;
+constexpr int LDS_END0 = LDS_SPARE + (kTileSurplus ? 1024 : 0);
+constexpr int LDS_STAGE = LDS_END0 + 2048 <= 160 * 1024 ? LDS_END0 : LDS_WTAB;  // (the lean instances do not use the offset table)
+constexpr int LDS_BYTES = LDS_END0 > LDS_STAGE + 2048 ? LDS_END0 : LDS_STAGE + 2048;
 static_assert(LDS_BYTES <= 160 * 1024, "fused dense block: LDS");
+static_assert(LDS_STAGE >= LDS_END0 || (LDS_STAGE == LDS_WTAB && !kTileSurplus), "staging must not share bytes with the spare KB");
 constexpr int NG = 6;  // accumulator groups: conv1..conv4, conv5 couts 0-31 / 32-63
 constexpr int MAXSTEPS = 80, MAXP = 480;
 constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
@@ -61,6 +76,7 @@ struct StepD {
   int nx_tile;      // 1 / 2: the next round's x chunks 0-1 / 2-3 are issued after the step's barrier (their buffers are free)
   int nx_q0, nx_q1; // the next round's weight piece groups [nx_q0, nx_q1) are issued after the step's barrier
   int Kclaim;       // claim == 2: thread 0's instructions younger than its ticket atomic
+  int copy_in;      // > 0 (lean instances): the halo columns of input group copy_in go from staging to their places behind this step's barrier
   int claim;        // 1: the workgroup's next tile is claimed during this step (its last neighbour flags have been seen), 2: the
                     // ticket is handed to all waves (through the LDS; readable behind the next barrier)
 };
@@ -162,7 +178,8 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
   }
   s.nsteps = ns;
   s.npieces = np;
-  for (int i = 1; i < ns; ++i) s.st[i].pre = s.st[i - 1].post ? 0 : 1;  // not across an epilogue (register pressure)
+  // not across an epilogue (register pressure), not into the first step of x1..x4 (its halo columns reach their places during the step before)
+  for (int i = 1; i < ns; ++i) s.st[i].pre = (s.st[i - 1].post || s.st[i].first_of_in > 0) ? 0 : 1;
   while (np % 8) {  // whole groups of eight: the padding re-loads piece 0 into a free slot
     s.wtab[np] = s.wtab[0];
     ++np;
@@ -178,6 +195,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     s.st[ti].tile_in = t;
     s.st[tf].flag_in = t;
     issue_step[t] = ti;
+    if (first_use[t] >= 1) s.st[first_use[t] - 1].copy_in = t;  // (ti < first_use - 1: the barrier of that step says the tile has landed)
   }
   // a tile buffer is never refilled while its previous content is still read: last read of the old input < issue step of the new one
   for (int t = 1; t <= 4; ++t)
@@ -185,6 +203,8 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
       const bool same_buf = s.st[j].tb == in_tb0(t) || s.st[j].tb == in_tb0(t) + 1;
       if (same_buf && s.st[j].in != t && j >= issue_step[t] && j <= last_use[t]) s.ok = 0;  // somebody else reads it while t owns it
       if (same_buf && s.st[j].in == t && j < issue_step[t]) s.ok = 0;
+      // lean instances: conv t's epilogue writes its tile into these buffers (step post_step[t]): nobody else may still read them
+      if (same_buf && s.st[j].in != t && j >= post_step[t] && j <= last_use[t]) s.ok = 0;
     }
   // read-ahead for the next round (always issued; behind the last round it fetches nothing useful): x chunks as soon as their
   // buffers hold nothing that is still read, the first weight groups as soon as their ring slots do
@@ -262,7 +282,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     if (d.claim == 2) d.Kclaim = seq - cseq;  // (handed over before this step issues anything)
     if (d.tile_in) {
       d.Kflag = seq - fseq[d.tile_in];
-      seq += TPW;  // two chunks
+      seq += (mode && kHalo) ? HPW : TPW;  // two chunks: whole (generic instance) or their ring
       tend[d.tile_in][0] = seq;
     }
     int q1 = (d.wp0 + RING) / 8;

@@ -241,7 +241,7 @@ int forward_body_h(const sr_rrdbnet_cfg* cfg, const NetPlanH& P, const FwdSpaceH
         d[4] = desc(buf, cat_ns, nxt, cat_ns, 1.f, 0.2f, buf, cat_ns, 1.f, nullptr, 0, 0.f);
       else
         d[4] = desc(buf, cat_ns, nxt, cat_ns, 1.f, 0.04f, buf, cat_ns, 0.2f, x_rrdb, cat_ns, 1.f);
-      rc = sr_conv3x3_chain_bf16(d, 5, sync, chain_call++, stream);
+      rc = sr::conv3x3_chain_bf16(d, 5, sync, chain_call++, stream, /*mids_scratch=*/!train);  // (train: x1..x4 are saved activations)
       if (rc) return rc;
     }
   }

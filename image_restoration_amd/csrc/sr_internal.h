@@ -68,6 +68,8 @@ void chain_watch(const int32_t* abort_word, hipStream_t stream);
 int chain_check(const char* who);
 const int32_t* abort_latch();  // device word raised behind a dense-block launch whose abort word went up (sr_abort_latch)
 int chain_mode();      // conv_bf16.hip: sr_set_conv_chain's value
+// conv_bf16.hip: sr_conv3x3_chain_bf16 with the caller's word that only the last conv's output is read afterwards
+int conv3x3_chain_bf16(const sr_conv3x3_desc* d, int nconv, int32_t* sync, int call_index, hipStream_t stream, bool mids_scratch);
 int forward_groups();  // image groups of the forward (sr_set_forward_groups; 0 = the path's own default)
 // Side streams + fork / join events of the calling thread for the grouped forward (created once per device).
 struct SideStreams {

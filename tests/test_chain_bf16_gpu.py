@@ -131,6 +131,39 @@ def test_fused_block_on_8_row_tiles_equals_conv_by_conv_bit_for_bit(cuda, n, h, 
         lib.sr_dev_set_fused_rows8(1)
 
 
+@pytest.mark.parametrize('n,h,w', [(16, 128, 128), (20, 128, 128), (12, 160, 100), (5, 208, 96), (2, 544, 544), (32, 32, 32), (6, 48, 72)])
+def test_fused_block_whose_intermediates_are_scratch_gives_the_same_output(cuda, n, h, w):
+    """The inference forward tells the dense block that nobody reads x1..x4 afterwards (rrdbnet_bf16.hip: `mids_scratch`; here through
+    the development switch).  A tile's inside then reaches the next conv through the LDS only and just its outermost ring — what the
+    neighbouring tiles fetch — is stored: the block's OUTPUT must still equal the conv-by-conv launches bit for bit, on whole and ragged
+    tiles, 16-row and 8-row instances, repeated calls on one sync block."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.sr_dev_set_chain_mids_scratch.argtypes = [C.c_int]
+    lib.sr_dev_set_chain_mids_scratch.restype = None
+    nf, gc = 64, 32
+    _lib.check(lib.sr_set_conv_chain(3), 'sr_set_conv_chain')
+    packs = _rdb(cuda, nf, gc, 3)
+    cat_a, nxt_a = _fresh(cuda, n, nf, gc, h, w, 5)
+    for src, pc, out, kw in _steps(cat_a, nxt_a, packs, nf, gc):
+        H.conv3x3_bf16(src, pc, out, **kw)
+    lib.sr_dev_set_chain_mids_scratch(1)
+    try:
+        sync = None
+        for rep in range(3):
+            cat_b, nxt_b = _fresh(cuda, n, nf, gc, h, w, 5)
+            _, sync = H.conv3x3_chain_bf16(_steps(cat_b, nxt_b, packs, nf, gc), sync, call_index=rep)
+            torch.cuda.synchronize()
+            assert int(sync[0]) == 0, 'a dependency wait timed out'
+            assert torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16]), rep
+            assert torch.equal(cat_a.buf[:, :nf // 16], cat_b.buf[:, :nf // 16]), 'the block input is not touched'
+        if h % 16 == 0 and n * (h // 16) * ((w + 31) // 32) >= 128:   # (where the 16-row fused kernel runs) the inside really stayed on chip
+            inner = cat_b.buf[:, nf // 16:, 1:15, 1:31].float()
+            assert bool((inner == 7.0).all()), 'expected the poison of _fresh() where nothing needs to be stored'
+    finally:
+        lib.sr_dev_set_chain_mids_scratch(0)
+
+
 @pytest.mark.parametrize('mode', [1, 2, 3])
 def test_chain_under_uneven_load_and_with_rrdb_residuals(cuda, mode):
     """Three chained dense blocks = one RRDB (the third closes with the RRDB residual, rrdbnet_arch.py:58-63) while a second stream

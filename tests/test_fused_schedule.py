@@ -44,7 +44,7 @@ IN_TB0 = {0: 0, 1: 4, 2: 0, 3: 2, 4: 4}
 IN_CHUNKS = {0: 4, 1: 2, 2: 2, 3: 2, 4: 2}
 
 
-def replay(s, following):
+def replay(s, following, columns_wave=False):
     """Issue sequence of one wave for one tile.  Returns (ops, per-step bookkeeping).  An op = (kind, payload, issue step) with step -1 =
     before the tile's first step (prologue or, for a following tile, the previous tile's read-ahead)."""
     mode, st, ring, ar = s['mode'], s['steps'], s['ring'], s['ar']
@@ -82,7 +82,13 @@ def replay(s, following):
         if d['claim'] == 2:
             pos[('hand',)] = len(ops)
         if d['tile_in']:
-            pos[('t', d['tile_in'], 0)] = issue('tile', (d['tile_in'], 0), i)
+            if mode != 0 and s['halo']:
+                # lean instances: only the ring of an x1..x4 tile comes through memory — HPW in-place pieces per wave, and waves 0 / 1
+                # issue the staging piece of the halo columns right behind theirs
+                for _ in range(s['hpw'] + (1 if columns_wave else 0)):
+                    pos[('t', d['tile_in'], 0)] = issue('halo', (d['tile_in'], 0), i)
+            else:
+                pos[('t', d['tile_in'], 0)] = issue('tile', (d['tile_in'], 0), i)
         for q in range(d['q0'], d['q1']):
             pos[('w', q)] = issue('w', q, i)
         if d['nx_tile']:
@@ -105,12 +111,13 @@ def replay(s, following):
     return ops, pos, waits
 
 
+@pytest.mark.parametrize('columns_wave', [False, True])
 @pytest.mark.parametrize('following', [False, True])
-def test_counted_waits_cover_what_each_step_reads(schedules, following):
+def test_counted_waits_cover_what_each_step_reads(schedules, following, columns_wave):
     for s in schedules:
         assert s['ok'] == 1 and s['npieces'] == 468 and s['nsteps'] <= 80
         st, ar = s['steps'], s['ar']
-        ops, pos, waits = replay(s, following)
+        ops, pos, waits = replay(s, following, columns_wave)
         for i, d in enumerate(st):
             done = waits[i] - d['K']                       # ops with position <= done are complete behind this step's wait
             need = []
@@ -131,6 +138,9 @@ def test_counted_waits_cover_what_each_step_reads(schedules, following):
                 assert waits[i] - d['Kflag'] >= pos[('flagfetch', d['tile_in'])]
             if d['claim'] == 2:                            # thread 0: the ticket atomic
                 assert pos[('hand',)] - d['Kclaim'] >= pos[('claim',)]
+            if d['copy_in']:                               # the halo columns are copied out of staging behind this step's barrier: landed
+                assert pos[('t', d['copy_in'], 0)] <= done, (s['mode'], i, 'staging not landed at the copy')
+                assert st[i + 1]['first_of_in'] == d['copy_in'] and st[i + 1]['pre'] == 0, 'the first use must not be read ahead of the copy'
 
 
 def test_ring_slots_and_tile_buffers_are_not_overwritten_while_read(schedules):
@@ -180,6 +190,16 @@ def test_ring_slots_and_tile_buffers_are_not_overwritten_while_read(schedules):
                         assert dj['in'] == t or j > last_use[t], (s['mode'], t, j)
                     if dj['tb'] in bufs and dj['in'] != t and j <= last_use[t]:
                         assert j < i, (s['mode'], t, j, 'another input is read from these buffers while t owns them')
+            if 1 <= d['post'] <= 4 and s['halo']:
+                # lean instances: conv t's epilogue writes its tile into input t's buffers at this step — whoever else used them is done,
+                # and input t's own readers come later, behind a barrier
+                t = d['post']
+                bufs = {IN_TB0[t], IN_TB0[t] + 1}
+                for j, dj in enumerate(st):
+                    if dj['tb'] in bufs and dj['in'] != t:
+                        assert j < i or j > last_use[t], (s['mode'], t, j, 'still read when the epilogue overwrites it')
+                    if dj['tb'] in bufs and dj['in'] == t:
+                        assert j > i + 1, (s['mode'], t, j)
             if d['nx_tile']:
                 bufs = {2 * (d['nx_tile'] - 1), 2 * (d['nx_tile'] - 1) + 1}
                 assert all(dj['tb'] not in bufs for dj in st[i:]), (s['mode'], i, 'next tile lands on data still read')

@@ -14,6 +14,7 @@ lib = _lib.load()
 lib.sr_set_conv_chain(3)
 lib.sr_dev_fused_phase_clocks.argtypes = [C.c_void_p]
 lib.sr_dev_set_fused_wave4.argtypes = [C.c_int]
+lib.sr_dev_set_chain_mids_scratch.argtypes = [C.c_int]
 dev = torch.device('cuda')
 for rnd in range(2):
     for n, h, w in ((16, 128, 128), (32, 128, 128), (4, 544, 544)):
@@ -21,8 +22,9 @@ for rnd in range(2):
         cat, nxt = _fresh(dev, n, 64, 32, h, w, 5)
         steps = _steps(cat, nxt, packs, 64, 32)
         row = []
-        for w4 in (0, 1):
+        for w4, scratch in ((0, 0), (1, 0), (0, 1), (1, 1)):   # scratch: x1..x4 are not read afterwards (the inference forward): only their ring is stored
             lib.sr_dev_set_fused_wave4(w4)
+            lib.sr_dev_set_chain_mids_scratch(scratch)
             for it in range(3):
                 _, sync = H.conv3x3_chain_bf16(steps, None, 0)
             torch.cuda.synchronize()
@@ -43,6 +45,7 @@ for rnd in range(2):
                 t = dbg.cpu().view(256, 64)
                 cyc.append(float((t[:, 61] - t[:, 60]).double().median()))
             lib.sr_dev_fused_phase_clocks(None)
-            row.append(f'{"four" if w4 else "eight"} waves {us:.1f} us, {sorted(cyc)[2]:.0f} cycles, abort {int(sync[0])}')
+            row.append(f'{"four" if w4 else "eight"} waves{", ring-only stores" if scratch else ""} {us:.1f} us, {sorted(cyc)[2]:.0f} cycles, abort {int(sync[0])}')
         print(f'n={n} {h}x{w}: ' + '   '.join(row), flush=True)
 lib.sr_dev_set_fused_wave4(0)
+lib.sr_dev_set_chain_mids_scratch(0)
