@@ -498,6 +498,14 @@ def main():
         from image_restoration_amd import _lib
         _lib.load().sr_dev_set_fused_rows8.argtypes = [C.c_int]
         _lib.load().sr_dev_set_fused_rows8(int(os.environ['SR_DEV_FUSED_ROWS8']))
+    if os.environ.get('SR_DEV_MIDS_SCRATCH'):   # A/B: -1 = the inference forward stores x1..x4 whole (as the training forward must)
+        from image_restoration_amd import _lib
+        _lib.load().sr_dev_set_chain_mids_scratch.argtypes = [C.c_int]
+        _lib.load().sr_dev_set_chain_mids_scratch(int(os.environ['SR_DEV_MIDS_SCRATCH']))
+    if os.environ.get('SR_DEV_FUSED_WAVE4'):    # A/B: 1 = the lean 16-row dense blocks on four waves of four rows
+        from image_restoration_amd import _lib
+        _lib.load().sr_dev_set_fused_wave4.argtypes = [C.c_int]
+        _lib.load().sr_dev_set_fused_wave4(int(os.environ['SR_DEV_FUSED_WAVE4']))
     if args.chain:
         from image_restoration_amd import _lib
         _lib.check(_lib.load().sr_set_conv_chain(args.chain), 'sr_set_conv_chain')

@@ -1347,7 +1347,7 @@ extern "C" void sr_dev_fused_grid_cap(int cap) { g_fused_grid_cap = cap; }
 
 // The dense block as rdb_fused_bf16_kernel when the five descriptors are one (64 + 4 x 32 channel) block over a single concat buffer and
 // every image's tiles fit the chip together; *launched says whether it ran.
-static int g_mids_scratch = 0;  // development / tests: every forward dense block as if its caller had said "x1..x4 are scratch"
+static int g_mids_scratch = 0;  // development / tests: 1 = every forward dense block as if its caller had said "x1..x4 are scratch", -1 = nobody's word counts
 extern "C" void sr_dev_set_chain_mids_scratch(int on) { g_mids_scratch = on; }
 static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int call_index, hipStream_t stream, bool* launched, bool mids_scratch) {
   *launched = false;
@@ -1459,7 +1459,7 @@ static int try_fused_dense_block(const sr_conv3x3_desc* d, int32_t* sync, int ca
     for (int k = 0; k < 4; ++k) P.mask[k] = P.lv[k].mask;
     P.mask_nb = P.lv[0].mask_nb;
     P.mask_slope = d[0].mask_slope;
-    P.mids_scratch = (lean && (mids_scratch || g_mids_scratch)) ? 1 : 0;
+    P.mids_scratch = (lean && g_mids_scratch >= 0 && (mids_scratch || g_mids_scratch > 0)) ? 1 : 0;
   }
   const bool prof = sr::prof_on();
   if (prof) {  // one record for the whole block: the FLOPs of its five convs, the bytes a block must move at least

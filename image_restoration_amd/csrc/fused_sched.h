@@ -196,6 +196,7 @@ constexpr Sched make_sched(const int mode) {  // 0 generic epilogues, 1 lean for
     s.st[tf].flag_in = t;
     issue_step[t] = ti;
     if (first_use[t] >= 1) s.st[first_use[t] - 1].copy_in = t;  // (ti < first_use - 1: the barrier of that step says the tile has landed)
+    if (t > 1 && ti <= first_use[t - 1] - 1) s.ok = 0;  // the staging KB still holds the previous input's columns
   }
   // a tile buffer is never refilled while its previous content is still read: last read of the old input < issue step of the new one
   for (int t = 1; t <= 4; ++t)

@@ -190,6 +190,10 @@ def test_ring_slots_and_tile_buffers_are_not_overwritten_while_read(schedules):
                         assert dj['in'] == t or j > last_use[t], (s['mode'], t, j)
                     if dj['tb'] in bufs and dj['in'] != t and j <= last_use[t]:
                         assert j < i, (s['mode'], t, j, 'another input is read from these buffers while t owns them')
+            if d['copy_in'] and s['halo']:
+                # one staging KB per chunk serves x1..x4 in turn: the next input's halo columns are issued only after this copy
+                later = [j for j, dj in enumerate(st) if dj['tile_in'] == d['copy_in'] + 1]
+                assert all(j > i for j in later), (s['mode'], d['copy_in'], later, i)
             if 1 <= d['post'] <= 4 and s['halo']:
                 # lean instances: conv t's epilogue writes its tile into input t's buffers at this step — whoever else used them is done,
                 # and input t's own readers come later, behind a barrier
