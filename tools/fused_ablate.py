@@ -48,7 +48,7 @@ for n in (16, 32):
 print('   '.join(out), ' abort', int(sync[0]))
 ''' % (ROOT, ROOT)
 
-NAMES = {1: 'no step barriers', 2: 'no epilogues', 4: 'no LDS-DMA', 8: 'no operand reads', 16: 'no flag polling', 32: 'no epilogue stores', 64: 'no vmcnt waits', 128: 'LDS read bytes of four rows per wave', 256: 'no weight DMA', 512: 'no tile DMA', 1024: 'hand-offs through L2', 4096: 'no DMA of the x1..x4 tiles'}
+NAMES = {1: 'no step barriers', 2: 'no epilogues', 4: 'no LDS-DMA', 8: 'no operand reads', 16: 'no flag polling', 32: 'no epilogue stores', 64: 'no vmcnt waits', 128: 'LDS read bytes of four rows per wave', 256: 'no weight DMA', 512: 'no tile DMA', 1024: 'hand-offs through L2', 4096: 'no DMA of the x1..x4 tiles', 8192: 'two 16x16x32 MFMAs per 32x32x16'}
 libs = sorted(glob.glob(os.path.join(ROOT, 'image_restoration_amd', 'lib', 'libsr_hip_abl*.so')), key=lambda p: int(re.findall(r'abl(\d+)', p)[0]))
 for rnd in range(2):
     for w4 in os.environ.get('SR_ABL_LAYOUTS', '0,1').split(','):   # '1': a variant that only fits the four-wave instance's registers
