@@ -112,6 +112,26 @@ def test_rrdbnet_bf16_vs_fp32_kernels(scale):
     assert psnr >= 40.0, psnr
 
 
+@pytest.mark.parametrize('n,h,w', [(16, 64, 64), (3, 128, 96), (8, 32, 32)])
+def test_rrdbnet_bf16_inference_forward_equals_the_training_forward_bit_for_bit(n, h, w):
+    """The inference forward tells every dense block that its x1..x4 are scratch (rrdbnet_bf16.hip: `mids_scratch` — only the ring a
+    neighbouring tile reads is stored, on four rotating concat buffers); the training forward keeps them whole as saved activations,
+    one buffer per block.  Same kernels, same arithmetic: the two outputs must be the same bits — on launches that take the 16-row
+    fused kernel, its 8-row instance and (small batches) the conv-by-conv path."""
+    from image_restoration_amd.archs.rrdbnet_arch import RRDBNet
+    torch.manual_seed(11)
+    net = RRDBNet(3, 3, scale=4, num_feat=64, num_block=3, num_grow_ch=32, compute_dtype='bf16').cuda()
+    x = torch.rand(n, 3, h, w, device='cuda')
+    with torch.no_grad():
+        y_inf = net(x)
+    y_train = net(x.clone().requires_grad_(True))
+    y_train.sum().backward()          # (the saved activations are read here: a ring-only store in THIS forward would show up as NaN / poison)
+    assert torch.equal(y_inf, y_train.detach())
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    from image_restoration_amd import watchdog
+    watchdog.verify('test: inference vs training forward')
+
+
 def test_rrdbnet_bf16_vs_reference_golden(golden):
     """bf16 path against the reference's own fp32 output for the full 23-block net (golden g_e_full23, generated by
     running the reference): PSNR >= 40 dB with peak = the reference output's range."""
