@@ -1,8 +1,10 @@
 """Randomised differential check of the one-launch dense blocks (sr_conv3x3_chain_bf16: fused dense-block kernel where eligible,
 persistent chain otherwise) and of the streaming conv against conv-by-conv launches of the per-tile kernel: random batch sizes,
 heights (multiples of 16, and a few that are not: fallback), widths that are no multiple of the 32-pixel tile, forward and transposed
-blocks, one or two residual sources, consecutive calls on one sync block.  Everything accumulates in the same order, so the
-comparison is BIT for bit.  Exit code 1 on any mismatch."""
+blocks, one or two residual sources, consecutive calls on one sync block; the fused kernel on eight waves of two rows or four waves of
+four (sr_dev_set_fused_wave4), and with the caller's word that x1..x4 are scratch (sr_dev_set_chain_mids_scratch: only the ring a
+neighbouring tile reads is stored — the OUTPUT is compared then).  Everything accumulates in the same order, so the comparison is
+BIT for bit.  Exit code 1 on any mismatch."""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -24,6 +26,8 @@ for it in range(N):
     transposed = random.random() < 0.4
     two_res = random.random() < 0.5
     mode = random.choice([2, 3, 3, 3])
+    wave4 = random.random() < 0.4
+    scratch = random.random() < 0.4
     g = torch.Generator().manual_seed(1000 + it)
     packs = []
     for k in range(1, 6):
@@ -58,14 +62,22 @@ for it in range(N):
         H.conv3x3_bf16(src, pc, out, **kw)
     lib.sr_set_conv_chain(mode)
     lib.sr_dev_set_conv_stream(1)
+    lib.sr_dev_set_fused_wave4(int(wave4))
+    lib.sr_dev_set_chain_mids_scratch(int(scratch))
     ok, sync = True, None
     for rep in range(2):
         cat_b, nxt_b = fresh()
         _, sync = H.conv3x3_chain_bf16(steps(cat_b, nxt_b), sync, call_index=rep)
         torch.cuda.synchronize()
-        ok = ok and int(sync[0]) == 0 and torch.equal(cat_a.buf, cat_b.buf) and torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16])
+        ok = ok and int(sync[0]) == 0 and torch.equal(nxt_a.buf[:, :nf // 16], nxt_b.buf[:, :nf // 16])
+        ok = ok and torch.equal(cat_a.buf[:, :nf // 16], cat_b.buf[:, :nf // 16])
+        if not (scratch and not transposed):   # (a forward block whose intermediates are scratch leaves their insides unwritten)
+            ok = ok and torch.equal(cat_a.buf, cat_b.buf)
+    lib.sr_dev_set_fused_wave4(0)
+    lib.sr_dev_set_chain_mids_scratch(0)
     bad += not ok
-    print(f'{it:3d} n={n} {h}x{w} mode={mode} transposed={int(transposed)} two_res={int(two_res)}: {"ok" if ok else "MISMATCH"}', flush=True)
+    print(f'{it:3d} n={n} {h}x{w} mode={mode} transposed={int(transposed)} two_res={int(two_res)} wave4={int(wave4)} scratch={int(scratch)}: '
+          f'{"ok" if ok else "MISMATCH"}', flush=True)
 lib.sr_set_conv_chain(3)
 print('mismatches:', bad)
 sys.exit(1 if bad else 0)
