@@ -58,6 +58,7 @@ constexpr int SC1 = 16;  // cache-policy bit of the buffer builtins: agent scope
 #define SR_FZ_AR 4
 #endif
 constexpr int AR = SR_FZ_AR;  // ring of weight fragments in registers: read AR-1 fragments ahead of their MFMAs
+static_assert(AR == 3 || AR == 4, "fragment ring: 3 and 4 are measured (equal); a build with 5 faults at launch (round 4), 6 fails the schedule");
 
 struct StepD {
   int in, chunk, g0, ng, dx0, ndx, tb;
